@@ -1,0 +1,62 @@
+"""Builds libdctfp.so (the HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+Standalone on purpose (python build_ext.py): importing ``dctdomain_amd`` requires the
+library to exist already."""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.join(ROOT, 'dctdomain_amd')
+CSRC = os.path.join(PKG_DIR, 'csrc')
+LIB_PATH = os.path.join(PKG_DIR, 'libdctfp.so')
+RECCUT_LIB_PATH = os.path.join(PKG_DIR, 'libreccut.so')
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', shutil.which('hipcc')):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found (set HIPCC or install ROCm under /opt/rocm)')
+
+
+def _stale(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> dctdomain_amd/libdctfp.so.  Returns the path."""
+    sources = [os.path.join(CSRC, 'dctfp.hip'), os.path.join(CSRC, 'kernels.hip.h'),
+               os.path.join(ROOT, 'include', 'dctfp.h')]
+    if force or _stale(LIB_PATH, sources):
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+               '-I', os.path.join(ROOT, 'include'), '-o', LIB_PATH, sources[0]]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    """Every native piece of the product (HIP kernels + host-side C++ helpers)."""
+    paths = [build_library(force=force, verbose=verbose)]
+    reccut_src = os.path.join(CSRC, 'reccut.cpp')
+    if os.path.exists(reccut_src):
+        if force or _stale(RECCUT_LIB_PATH, [reccut_src, os.path.join(ROOT, 'include', 'reccut.h')]):
+            cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-shared', '-fPIC',
+                   '-I', os.path.join(ROOT, 'include'), '-o', RECCUT_LIB_PATH, reccut_src]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.run(cmd, check=True)
+        paths.append(RECCUT_LIB_PATH)
+    return paths
+
+
+if __name__ == '__main__':
+    print(build_all(force=True, verbose=True))

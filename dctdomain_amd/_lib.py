@@ -1,0 +1,153 @@
+"""ctypes binding of libdctfp.so (include/dctfp.h).  No fallback: if the HIP library is
+missing or no MI355X is visible, everything here raises."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdctfp.so')
+
+DCTFP_OK = 0
+DCTFP_ERR_INVALID = -1
+DCTFP_ERR_SHAPE = -2
+DCTFP_ERR_HIP = -3
+DCTFP_ERR_NOMEM = -4
+DCTFP_ERR_LIMIT = -5
+DCTFP_MAX_N = 8
+DCTFP_MAX_M = 128
+DCTFP_F32 = 0
+DCTFP_F64 = 1
+
+#: numpy image of ``dctfp_piece`` (include/dctfp.h)
+PIECE_DTYPE = np.dtype([('row_start', '<i8'), ('n_rows', '<i4'), ('domain', '<i4'),
+                        ('seq', '<i4'), ('reserved', '<i4')], align=True)
+assert PIECE_DTYPE.itemsize == 24
+
+
+class Layer(C.Structure):
+    """``dctfp_layer`` (include/dctfp.h)."""
+    _fields_ = [('seq_data', C.POINTER(C.c_void_p)), ('ld', C.c_int64), ('n_cols', C.c_int32),
+                ('dtype', C.c_int32), ('n_keep', C.c_int32), ('m_keep', C.c_int32),
+                ('out_offset', C.c_int32), ('reserved', C.c_int32)]
+
+
+class DctfpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'libdctfp error {code}: {msg}')
+        self.code = code
+        self.msg = msg
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+EXPORTS = ('dctfp_version', 'dctfp_last_error', 'dctfp_create', 'dctfp_destroy', 'dctfp_quantize',
+           'dctfp_idct_quant', 'dctfp_scale', 'dctfp_gather_rows', 'dctfp_set_option',
+           'dctfp_get_option', 'dctfp_profile')
+
+
+def load():
+    """Loads libdctfp.so; raises ImportError when it has not been built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f'{LIB_PATH} is missing: build the HIP extension first '
+                f'(python -c "import __graft_entry__ as g; g.build()" or python build_ext.py). '
+                f'dctdomain_amd has no CPU fallback.')
+        lib = C.CDLL(LIB_PATH)
+        lib.dctfp_version.restype = C.c_int
+        lib.dctfp_last_error.restype = C.c_char_p
+        lib.dctfp_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.dctfp_destroy.argtypes = [C.c_void_p]
+        lib.dctfp_quantize.argtypes = [C.c_void_p, C.POINTER(Layer), C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+        lib.dctfp_idct_quant.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
+                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dctfp_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        lib.dctfp_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
+                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        lib.dctfp_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        lib.dctfp_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
+        lib.dctfp_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        for fn in EXPORTS:
+            if fn != 'dctfp_last_error':
+                getattr(lib, fn).restype = C.c_int
+        _lib = lib
+        return lib
+
+
+def check(rc: int):
+    """Maps a return code to the exception the reference would raise."""
+    if rc == DCTFP_OK:
+        return
+    msg = load().dctfp_last_error().decode('utf-8', 'replace')
+    if rc == DCTFP_ERR_SHAPE:
+        raise ValueError(msg)            # numpy's reshape failure at src/fingerprint.py:194
+    if rc == DCTFP_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise DctfpError(rc, msg)
+
+
+class Context:
+    """One ``dctfp_ctx`` (per process and device)."""
+
+    def __init__(self, device: int):
+        lib = load()
+        handle = C.c_void_p()
+        check(lib.dctfp_create(int(device), C.byref(handle)))
+        self._lib = lib
+        self._h = handle
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            self._lib.dctfp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError('context is closed')
+        return self._h
+
+    def set_option(self, name: str, value: int):
+        check(self._lib.dctfp_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64()
+        check(self._lib.dctfp_get_option(self.handle, name.encode(), C.byref(v)))
+        return v.value
+
+    def profile(self):
+        """(ms[2], launches[2]) of stage A / stage B since the last call ("profile" option on)."""
+        ms = (C.c_double * 2)()
+        n = (C.c_int64 * 2)()
+        check(self._lib.dctfp_profile(self.handle, ms, n))
+        return [ms[0], ms[1]], [n[0], n[1]]
+
+
+_contexts = {}
+_ctx_lock = threading.Lock()
+
+
+def get_context(device: int) -> Context:
+    with _ctx_lock:
+        key = (os.getpid(), int(device))
+        ctx = _contexts.get(key)
+        if ctx is None:
+            ctx = Context(device)
+            _contexts[key] = ctx
+        return ctx

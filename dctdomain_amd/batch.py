@@ -1,0 +1,159 @@
+"""Ragged-batch front end of the fingerprint kernels: many sequences, several layers,
+several domains per sequence, one ``dctfp_quantize`` call.
+
+The reference processes one ``Fingerprint`` at a time inside a multiprocessing pool
+(mgtools/DCTdomain src/make_db.py:36-51).  Here the embeddings of a whole batch stay on the
+GPU as torch tensors and the domain strings are turned into one piece table."""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .domains import split_domain
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return _lib.DCTFP_F32
+    if t.dtype == torch.float64:
+        return _lib.DCTFP_F64
+    raise TypeError(f'embedding dtype {t.dtype}: use float32 or float64')
+
+
+class PieceTable:
+    """Host-side piece table of a batch (numpy image of ``dctfp_piece[]``)."""
+
+    def __init__(self, seq_rows: Sequence[int], domains: Sequence[Sequence[str]]):
+        """``seq_rows[s]`` rows of sequence ``s``; ``domains[s]`` its domain strings.
+        Domains whose cleaned piece list is empty are skipped, as the reference does
+        (src/fingerprint.py:190-191)."""
+        recs = []
+        self.keys: List[str] = []      # cleaned key per output row
+        self.owner: List[int] = []     # sequence index per output row
+        self.source: List[int] = []    # index of the domain string inside domains[s]
+        self.lengths: List[int] = []   # rows per output row
+        d = 0
+        for s, (n_rows, doms) in enumerate(zip(seq_rows, domains)):
+            for di, dom in enumerate(doms):
+                pieces, key = split_domain(dom, int(n_rows))
+                if not pieces:
+                    continue
+                for start, n in pieces:
+                    recs.append((start, n, d, s, 0))
+                self.keys.append(key)
+                self.owner.append(s)
+                self.source.append(di)
+                self.lengths.append(sum(n for _, n in pieces))
+                d += 1
+        self.n_domains = d
+        self.pieces = np.array(recs, dtype=_lib.PIECE_DTYPE) if recs else np.zeros(0, dtype=_lib.PIECE_DTYPE)
+        self.seq_rows = np.ascontiguousarray(np.asarray(seq_rows, dtype=np.int64))
+
+    @classmethod
+    def whole_sequences(cls, seq_rows: Sequence[int]):
+        """One domain ``1-L`` per sequence, built without string parsing (bench path)."""
+        self = cls.__new__(cls)
+        sr = np.ascontiguousarray(np.asarray(seq_rows, dtype=np.int64))
+        n = len(sr)
+        p = np.zeros(n, dtype=_lib.PIECE_DTYPE)
+        p['row_start'] = 0
+        p['n_rows'] = sr
+        p['domain'] = np.arange(n)
+        p['seq'] = np.arange(n)
+        self.pieces = p
+        self.seq_rows = sr
+        self.n_domains = n
+        self.keys = [f'1-{int(v)}' for v in sr]
+        self.owner = list(range(n))
+        self.source = [0] * n
+        self.lengths = [int(v) for v in sr]
+        return self
+
+
+class LayerBatch:
+    """One embedding layer of a batch: per-sequence device matrices sharing D, dtype and ld.
+
+    ``tensors`` is either one 2-D tensor holding all sequences back to back (then
+    ``row_offsets`` gives each sequence's first row) or a list of 2-D tensors."""
+
+    def __init__(self, tensors, n_keep: int, m_keep: int, row_offsets=None):
+        if isinstance(tensors, torch.Tensor):
+            big = tensors
+            if big.dim() != 2 or big.stride(1) != 1:
+                raise ValueError('layer tensor must be 2-D with contiguous channels')
+            if row_offsets is None:
+                row_offsets = [0]
+            esz = big.element_size()
+            base = big.data_ptr()
+            self.ptrs = np.uint64(base) + np.asarray(row_offsets, dtype=np.uint64) * np.uint64(big.stride(0) * esz)
+            self.ld = big.stride(0)
+            self.n_cols = big.shape[1]
+            self.dtype = _dtype_code(big)
+            self.device = big.device
+            self._keep = [big]
+        else:
+            ts = list(tensors)
+            if not ts:
+                raise ValueError('empty layer')
+            t0 = ts[0]
+            for t in ts:
+                if t.dim() != 2 or t.stride(1) != 1 or t.shape[1] != t0.shape[1] or t.dtype != t0.dtype \
+                        or t.device != t0.device or (t.shape[0] > 1 and t.stride(0) != t0.stride(0)):
+                    raise ValueError('all sequences of a layer must share D, dtype, device and row stride')
+            self.ptrs = np.array([t.data_ptr() for t in ts], dtype=np.uint64)
+            self.ld = t0.stride(0) if t0.shape[0] > 1 else t0.shape[1]
+            self.n_cols = t0.shape[1]
+            self.dtype = _dtype_code(t0)
+            self.device = t0.device
+            self._keep = ts
+        if self.device.type != 'cuda':
+            raise ValueError('embeddings must live on the GPU (torch device "cuda")')
+        self.ptrs = np.ascontiguousarray(self.ptrs, dtype=np.uint64)   # host array of device pointers
+        self.n_keep = int(n_keep)
+        self.m_keep = int(m_keep)
+
+
+def quantize_batch(layers: Sequence[LayerBatch], table: PieceTable, out: torch.Tensor = None,
+                   ctx: _lib.Context = None, stream=None) -> torch.Tensor:
+    """Runs ``dctfp_quantize`` (include/dctfp.h) and returns the int8 tensor
+    ``(table.n_domains, sum n_i*m_i)`` on the layers' device.  Asynchronous with respect
+    to the host: the result is ordered on the given / current torch stream."""
+    if not layers:
+        raise ValueError('no layers')
+    device = layers[0].device
+    total = sum(l.n_keep * l.m_keep for l in layers)
+    if out is None:
+        out = torch.empty((table.n_domains, total), dtype=torch.int8, device=device)
+    elif out.dtype != torch.int8 or out.dim() != 2 or out.shape[0] < table.n_domains or out.shape[1] < total \
+            or out.stride(1) != 1 or out.device != device:
+        raise ValueError('out must be an int8 (n_domains, >= sum n*m) tensor on the same device')
+    if table.n_domains == 0:
+        return out
+    if ctx is None:
+        ctx = _lib.get_context(device.index if device.index is not None else torch.cuda.current_device())
+    n_seq = len(table.seq_rows)
+    arr = (_lib.Layer * len(layers))()
+    off = 0
+    for i, l in enumerate(layers):
+        if len(l.ptrs) != n_seq:
+            raise ValueError(f'layer {i} has {len(l.ptrs)} sequences, the piece table {n_seq}')
+        arr[i].seq_data = C.cast(C.c_void_p(l.ptrs.ctypes.data), C.POINTER(C.c_void_p))
+        arr[i].ld = l.ld
+        arr[i].n_cols = l.n_cols
+        arr[i].dtype = l.dtype
+        arr[i].n_keep = l.n_keep
+        arr[i].m_keep = l.m_keep
+        arr[i].out_offset = off
+        off += l.n_keep * l.m_keep
+    if stream is None:
+        stream = torch.cuda.current_stream(device)
+    rc = ctx._lib.dctfp_quantize(ctx.handle, arr, len(layers), n_seq, table.seq_rows.ctypes.data,
+                                 table.pieces.ctypes.data, len(table.pieces), table.n_domains,
+                                 out.data_ptr(), out.stride(0), C.c_void_p(stream.cuda_stream))
+    _lib.check(rc)
+    return out

@@ -1,0 +1,741 @@
+// libdctfp.so -- host side of the C ABI declared in include/dctfp.h.
+// Builds the job tables of a ragged batch, owns the cosine bases and the float64
+// scratch, and launches the gfx950 kernels of kernels.hip.h.  No CPU compute path:
+// every entry point needs the GPU.
+#include "dctfp.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#define DCTFP_MAX_N_K DCTFP_MAX_N
+#define DCTFP_MAX_M_K DCTFP_MAX_M
+#include "kernels.hip.h"
+
+using namespace dctfp;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(DCTFP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// cos(pi p / q) in long double with exact integer argument reduction (p >= 0, q > 0).
+long double cospi_ratio_host(int64_t p, int64_t q) {
+    p %= 2 * q;
+    if (p > q) p = 2 * q - p;
+    long double sign = 1.0L;
+    if (2 * p > q) {
+        p = q - p;
+        sign = -1.0L;
+    }
+    const long double pi = 3.141592653589793238462643383279502884L;
+    long double r = (4 * p > q) ? sinl(pi * (long double)(q - 2 * p) / (long double)(2 * q))
+                                : cosl(pi * (long double)p / (long double)q);
+    return sign * r;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return DCTFP_OK;
+        if (p) {
+            hipError_t e = hipFree(p);  // device-synchronising: earlier launches are done with it
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return fail(DCTFP_ERR_HIP, "hipFree: %s", hipGetErrorString(e));
+        }
+        size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            want = bytes;
+            e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(DCTFP_ERR_NOMEM, "hipMalloc(%zu bytes): %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return DCTFP_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Staging {  // pinned host buffer + the event after its last H2D copy
+    void* p = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    int ensure(size_t bytes) {
+        if (pending) {
+            hipError_t e = hipEventSynchronize(ev);
+            pending = false;
+            if (e != hipSuccess) return fail(DCTFP_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+        }
+        if (!ev) {
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) return fail(DCTFP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+        }
+        if (bytes <= cap) return DCTFP_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 2 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(DCTFP_ERR_NOMEM, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return DCTFP_OK;
+    }
+    void release() {
+        if (pending && ev) (void)hipEventSynchronize(ev);
+        if (p) (void)hipHostFree(p);
+        if (ev) (void)hipEventDestroy(ev);
+        p = nullptr;
+        ev = nullptr;
+        cap = 0;
+    }
+};
+
+struct StEntry {  // stage-B basis  St[d][c] (ldy x cp), zero padded
+    double* dev = nullptr;
+    int ldy = 0, cp = 0;
+    uint64_t last_use = 0;
+};
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    int which = 0;
+};
+
+}  // namespace
+
+struct dctfp_ctx {
+    int device = 0;
+    int64_t opt_stage_b = 1, opt_a_waves = 4, opt_a_unroll = 8, opt_profile = 0, opt_ws_mb = 4096;
+    DevBuf tables[2];
+    Staging staging[2];
+    int flip = 0;
+    DevBuf ws;       // yprime
+    DevBuf scratch;  // generic idct_quant fs
+    std::map<std::pair<int, int>, StEntry> st_cache;
+    uint64_t tick = 0;
+    std::vector<EventPair> events;
+    size_t events_used = 0;
+    double prof_ms[2] = {0, 0};
+    int64_t prof_n[2] = {0, 0};
+};
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int get_st(dctfp_ctx* ctx, int n_cols, int m, hipStream_t stream, StEntry** out) {
+    auto key = std::make_pair(n_cols, m);
+    auto it = ctx->st_cache.find(key);
+    if (it != ctx->st_cache.end()) {
+        it->second.last_use = ++ctx->tick;
+        *out = &it->second;
+        return DCTFP_OK;
+    }
+    if (ctx->st_cache.size() >= 32) {  // drop the least recently used basis
+        auto victim = ctx->st_cache.begin();
+        for (auto i = ctx->st_cache.begin(); i != ctx->st_cache.end(); ++i)
+            if (i->second.last_use < victim->second.last_use) victim = i;
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(victim->second.dev);
+        ctx->st_cache.erase(victim);
+    }
+    const int ldy = (int)align_up((size_t)n_cols, 32);
+    const int cp = (int)align_up((size_t)m, 16);
+    // S[c][d] = sum_{k=1}^{m-1} cos(pi k (2c+1) / (2m)) cos(pi k (2d+1) / (2D)): forward DCT-II
+    // over the D channels, keep m, inverse DCT of length m -- k = 0 and the common
+    // normalisation dropped (the per-row min-max scale removes both).
+    std::vector<long double> ca((size_t)m * m), cb((size_t)m * n_cols);
+    for (int k = 1; k < m; ++k) {
+        for (int c = 0; c < m; ++c) ca[(size_t)k * m + c] = cospi_ratio_host((int64_t)k * (2 * c + 1), 2 * (int64_t)m);
+        for (int d = 0; d < n_cols; ++d)
+            cb[(size_t)k * n_cols + d] = cospi_ratio_host((int64_t)k * (2 * (int64_t)d + 1), 2 * (int64_t)n_cols);
+    }
+    std::vector<double> host((size_t)ldy * cp, 0.0);
+    std::vector<long double> col(m);
+    for (int d = 0; d < n_cols; ++d) {
+        for (int c = 0; c < m; ++c) col[c] = 0.0L;
+        for (int k = 1; k < m; ++k) {
+            const long double b = cb[(size_t)k * n_cols + d];
+            const long double* a = &ca[(size_t)k * m];
+            for (int c = 0; c < m; ++c) col[c] += a[c] * b;
+        }
+        for (int c = 0; c < m; ++c) host[(size_t)d * cp + c] = (double)col[c];
+    }
+    StEntry e;
+    e.ldy = ldy;
+    e.cp = cp;
+    HIP_TRY(hipMalloc((void**)&e.dev, host.size() * sizeof(double)));
+    hipError_t err = hipMemcpy(e.dev, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        (void)hipFree(e.dev);
+        return fail(DCTFP_ERR_HIP, "hipMemcpy(St): %s", hipGetErrorString(err));
+    }
+    (void)stream;
+    e.last_use = ++ctx->tick;
+    auto ins = ctx->st_cache.emplace(key, e);
+    *out = &ins.first->second;
+    return DCTFP_OK;
+}
+
+template <int N>
+InvTab<N> make_inv() {
+    InvTab<N> t;
+    if constexpr (N > 1) {
+        for (int j = 0; j < N; ++j)
+            for (int k = 1; k < N; ++k)
+                t.c[j * (N - 1) + (k - 1)] = (double)cospi_ratio_host((int64_t)k * (2 * j + 1), 2 * (int64_t)N);
+    } else {
+        t.c[0] = 0.0;
+    }
+    return t;
+}
+
+struct AParams {
+    const JobA* jobs;
+    const PieceA* pieces;
+    const double* basis;
+    double* yprime;
+    int n_cols;
+    int64_t ld;
+    int ldy;
+    int n_slabs;
+    unsigned grid;
+    hipStream_t stream;
+};
+
+template <typename T, int N, int VEC, int WAVES, int UNROLL>
+void launch_a_impl(const AParams& p) {
+    static const InvTab<N> inv = make_inv<N>();
+    hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream, p.jobs,
+                       p.pieces, p.basis, p.yprime, p.n_cols, p.ld, p.ldy, p.n_slabs, inv);
+}
+
+template <typename T, int N, int VEC>
+void launch_a_cfg(const AParams& p, int waves, int unroll) {
+    if (waves == 8) {
+        if (unroll == 4) launch_a_impl<T, N, VEC, 8, 4>(p);
+        else launch_a_impl<T, N, VEC, 8, 8>(p);
+    } else if (waves == 16) {
+        if (unroll == 4) launch_a_impl<T, N, VEC, 16, 4>(p);
+        else launch_a_impl<T, N, VEC, 16, 8>(p);
+    } else {
+        if (unroll == 4) launch_a_impl<T, N, VEC, 4, 4>(p);
+        else launch_a_impl<T, N, VEC, 4, 8>(p);
+    }
+}
+
+template <typename T, int VEC>
+void launch_a_n(const AParams& p, int n, int waves, int unroll) {
+    switch (n) {
+        case 2: launch_a_cfg<T, 2, VEC>(p, waves, unroll); break;
+        case 3: launch_a_cfg<T, 3, VEC>(p, waves, unroll); break;
+        case 4: launch_a_impl<T, 4, VEC, 4, 4>(p); break;
+        case 5: launch_a_impl<T, 5, VEC, 4, 4>(p); break;
+        case 6: launch_a_impl<T, 6, VEC, 4, 4>(p); break;
+        case 7: launch_a_impl<T, 7, VEC, 4, 4>(p); break;
+        default: launch_a_impl<T, 8, VEC, 4, 4>(p); break;
+    }
+}
+
+void launch_a(const AParams& p, int dtype, int vec, int n, int waves, int unroll) {
+    if (dtype == DCTFP_F32) {
+        if (vec == 4) launch_a_n<float, 4>(p, n, waves, unroll);
+        else launch_a_n<float, 1>(p, n, waves, unroll);
+    } else {
+        if (vec == 2) launch_a_n<double, 2>(p, n, waves, unroll);
+        else launch_a_n<double, 1>(p, n, waves, unroll);
+    }
+}
+
+void launch_b_mfma(int nt, unsigned grid, hipStream_t s, const double* yp, int64_t rows, int ldy, const double* st,
+                   const JobB* jobs, int n, int m, int8_t* out) {
+#define DCTFP_B_CASE(NT)                                                                                          \
+    case NT:                                                                                                      \
+        hipLaunchKernelGGL((stage_b_mfma_kernel<NT>), dim3(grid), dim3(256), 0, s, yp, rows, ldy, st, jobs, n, m, \
+                           out);                                                                                  \
+        break;
+    switch (nt) {
+        DCTFP_B_CASE(1)
+        DCTFP_B_CASE(2)
+        DCTFP_B_CASE(3)
+        DCTFP_B_CASE(4)
+        DCTFP_B_CASE(5)
+        DCTFP_B_CASE(6)
+        DCTFP_B_CASE(7)
+        default:
+            hipLaunchKernelGGL((stage_b_mfma_kernel<8>), dim3(grid), dim3(256), 0, s, yp, rows, ldy, st, jobs, n, m,
+                               out);
+            break;
+    }
+#undef DCTFP_B_CASE
+}
+
+int prof_begin(dctfp_ctx* ctx, int which, hipStream_t s, EventPair** ep) {
+    *ep = nullptr;
+    if (!ctx->opt_profile) return DCTFP_OK;
+    if (ctx->events_used == ctx->events.size()) {
+        EventPair e;
+        HIP_TRY(hipEventCreate(&e.a));
+        HIP_TRY(hipEventCreate(&e.b));
+        ctx->events.push_back(e);
+    }
+    EventPair& e = ctx->events[ctx->events_used++];
+    e.which = which;
+    HIP_TRY(hipEventRecord(e.a, s));
+    *ep = &e;
+    return DCTFP_OK;
+}
+
+int prof_end(EventPair* ep, hipStream_t s) {
+    if (!ep) return DCTFP_OK;
+    HIP_TRY(hipEventRecord(ep->b, s));
+    return DCTFP_OK;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int dctfp_version(void) { return DCTFP_VERSION; }
+
+const char* dctfp_last_error(void) { return g_err.c_str(); }
+
+int dctfp_create(int device, dctfp_ctx** out) {
+    if (!out) return fail(DCTFP_ERR_INVALID, "dctfp_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(DCTFP_ERR_INVALID, "dctfp_create: device %d of %d", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(DCTFP_ERR_HIP, "dctfp_create: device %d is %s; this library is built for gfx950 only", device,
+                    prop.gcnArchName);
+    dctfp_ctx* ctx = new (std::nothrow) dctfp_ctx();
+    if (!ctx) return fail(DCTFP_ERR_NOMEM, "dctfp_create: out of host memory");
+    ctx->device = device;
+    *out = ctx;
+    return DCTFP_OK;
+}
+
+int dctfp_destroy(dctfp_ctx* ctx) {
+    if (!ctx) return DCTFP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& t : ctx->tables) t.release();
+    for (auto& s : ctx->staging) s.release();
+    ctx->ws.release();
+    ctx->scratch.release();
+    for (auto& kv : ctx->st_cache) (void)hipFree(kv.second.dev);
+    for (auto& e : ctx->events) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    delete ctx;
+    return DCTFP_OK;
+}
+
+int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return fail(DCTFP_ERR_INVALID, "dctfp_set_option: NULL argument");
+    std::string n(name);
+    if (n == "stage_b") {
+        if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "stage_b must be 0 or 1");
+        ctx->opt_stage_b = value;
+    } else if (n == "a_waves") {
+        if (value != 4 && value != 8 && value != 16) return fail(DCTFP_ERR_INVALID, "a_waves must be 4, 8 or 16");
+        ctx->opt_a_waves = value;
+    } else if (n == "a_unroll") {
+        if (value != 4 && value != 8) return fail(DCTFP_ERR_INVALID, "a_unroll must be 4 or 8");
+        ctx->opt_a_unroll = value;
+    } else if (n == "profile") {
+        ctx->opt_profile = value ? 1 : 0;
+    } else if (n == "workspace_mb") {
+        if (value < 16) return fail(DCTFP_ERR_INVALID, "workspace_mb must be >= 16");
+        ctx->opt_ws_mb = value;
+    } else {
+        return fail(DCTFP_ERR_INVALID, "unknown option '%s'", name);
+    }
+    return DCTFP_OK;
+}
+
+int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
+    if (!ctx || !name || !value) return fail(DCTFP_ERR_INVALID, "dctfp_get_option: NULL argument");
+    std::string n(name);
+    if (n == "stage_b") *value = ctx->opt_stage_b;
+    else if (n == "a_waves") *value = ctx->opt_a_waves;
+    else if (n == "a_unroll") *value = ctx->opt_a_unroll;
+    else if (n == "profile") *value = ctx->opt_profile;
+    else if (n == "workspace_mb") *value = ctx->opt_ws_mb;
+    else return fail(DCTFP_ERR_INVALID, "unknown option '%s'", name);
+    return DCTFP_OK;
+}
+
+int dctfp_profile(dctfp_ctx* ctx, double ms[2], int64_t launches[2]) {
+    if (!ctx || !ms || !launches) return fail(DCTFP_ERR_INVALID, "dctfp_profile: NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (size_t i = 0; i < ctx->events_used; ++i) {
+        EventPair& e = ctx->events[i];
+        HIP_TRY(hipEventSynchronize(e.b));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e.a, e.b));
+        ctx->prof_ms[e.which] += t;
+        ctx->prof_n[e.which] += 1;
+    }
+    ctx->events_used = 0;
+    for (int i = 0; i < 2; ++i) {
+        ms[i] = ctx->prof_ms[i];
+        launches[i] = ctx->prof_n[i];
+        ctx->prof_ms[i] = 0;
+        ctx->prof_n[i] = 0;
+    }
+    return DCTFP_OK;
+}
+
+int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, int32_t n_seq,
+                   const int64_t* seq_rows, const dctfp_piece* pieces, int64_t n_pieces, int64_t n_domains,
+                   int8_t* out, int64_t out_stride, void* stream_v) {
+    if (!ctx) return fail(DCTFP_ERR_INVALID, "dctfp_quantize: ctx is NULL");
+    if (n_layers < 0 || n_seq < 0 || n_pieces < 0 || n_domains < 0)
+        return fail(DCTFP_ERR_INVALID, "dctfp_quantize: negative count");
+    if (n_layers == 0 || n_domains == 0) return DCTFP_OK;
+    if (!layers || !seq_rows || !pieces || !out) return fail(DCTFP_ERR_INVALID, "dctfp_quantize: NULL argument");
+    if (n_pieces >= (int64_t)1 << 31 || n_domains >= (int64_t)1 << 31)
+        return fail(DCTFP_ERR_LIMIT, "dctfp_quantize: more than 2^31 pieces or domains in one call");
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    // ---- validate the piece table, domain lengths --------------------------------
+    std::vector<uint32_t> dom_len((size_t)n_domains, 0), dom_first((size_t)n_domains, 0), dom_np((size_t)n_domains, 0);
+    {
+        int64_t prev = -1;
+        for (int64_t i = 0; i < n_pieces; ++i) {
+            const dctfp_piece& pc = pieces[i];
+            if (pc.domain < 0 || pc.domain >= n_domains || pc.domain < prev)
+                return fail(DCTFP_ERR_INVALID, "piece %lld: domain %d out of order or range", (long long)i, pc.domain);
+            if (pc.seq < 0 || pc.seq >= n_seq)
+                return fail(DCTFP_ERR_INVALID, "piece %lld: sequence %d out of range", (long long)i, pc.seq);
+            if (pc.n_rows <= 0 || pc.row_start < 0 || pc.row_start + pc.n_rows > seq_rows[pc.seq])
+                return fail(DCTFP_ERR_INVALID, "piece %lld: rows [%lld, +%d) outside sequence %d of %lld rows",
+                            (long long)i, (long long)pc.row_start, pc.n_rows, pc.seq, (long long)seq_rows[pc.seq]);
+            if (pc.domain != prev) dom_first[pc.domain] = (uint32_t)i;
+            if ((uint64_t)dom_len[pc.domain] + (uint64_t)pc.n_rows > 0x7fffffffu)
+                return fail(DCTFP_ERR_LIMIT, "domain %d longer than 2^31 rows", pc.domain);
+            dom_len[pc.domain] += (uint32_t)pc.n_rows;
+            dom_np[pc.domain] += 1;
+            prev = pc.domain;
+        }
+        for (int64_t d = 0; d < n_domains; ++d)
+            if (dom_np[d] == 0) return fail(DCTFP_ERR_INVALID, "domain %lld has no piece", (long long)d);
+    }
+    uint32_t min_len = 0xffffffffu;
+    for (int64_t d = 0; d < n_domains; ++d) min_len = std::min(min_len, dom_len[d]);
+
+    for (int32_t l = 0; l < n_layers; ++l) {
+        const dctfp_layer& ly = layers[l];
+        if (!ly.seq_data) return fail(DCTFP_ERR_INVALID, "layer %d: seq_data is NULL", l);
+        if (ly.dtype != DCTFP_F32 && ly.dtype != DCTFP_F64) return fail(DCTFP_ERR_INVALID, "layer %d: dtype %d", l, ly.dtype);
+        if (ly.n_cols <= 0 || ly.ld < ly.n_cols) return fail(DCTFP_ERR_INVALID, "layer %d: n_cols %d ld %lld", l, ly.n_cols, (long long)ly.ld);
+        if (ly.n_keep < 1 || ly.m_keep < 1) return fail(DCTFP_ERR_INVALID, "layer %d: qdim (%d, %d)", l, ly.n_keep, ly.m_keep);
+        if (ly.n_keep > DCTFP_MAX_N || ly.m_keep > DCTFP_MAX_M)
+            return fail(DCTFP_ERR_LIMIT, "layer %d: qdim (%d, %d) above the supported (%d, %d)", l, ly.n_keep, ly.m_keep, DCTFP_MAX_N, DCTFP_MAX_M);
+        if (ly.out_offset < 0 || (int64_t)ly.out_offset + (int64_t)ly.n_keep * ly.m_keep > out_stride)
+            return fail(DCTFP_ERR_INVALID, "layer %d: block [%d, +%d) outside out_stride %lld", l, ly.out_offset, ly.n_keep * ly.m_keep, (long long)out_stride);
+        for (int32_t s = 0; s < n_seq; ++s)
+            if (!ly.seq_data[s] && seq_rows[s] > 0) return fail(DCTFP_ERR_INVALID, "layer %d: sequence %d has no data", l, s);
+        // the reference's reshape failure (src/fingerprint.py:194): L_d < n or D < m
+        if ((int64_t)min_len < ly.n_keep) {
+            for (int64_t d = 0; d < n_domains; ++d)
+                if ((int64_t)dom_len[d] < ly.n_keep)
+                    return fail(DCTFP_ERR_SHAPE, "cannot reshape array of size %lld into shape (%d,) [domain %lld has %u rows < n = %d]",
+                                (long long)dom_len[d] * std::min(ly.m_keep, ly.n_cols), ly.n_keep * ly.m_keep, (long long)d, dom_len[d], ly.n_keep);
+        }
+        if (ly.n_cols < ly.m_keep)
+            return fail(DCTFP_ERR_SHAPE, "cannot reshape array of size %d into shape (%d,) [layer %d has %d channels < m = %d]",
+                        ly.n_keep * ly.n_cols, ly.n_keep * ly.m_keep, l, ly.n_cols, ly.m_keep);
+    }
+
+    // ---- groups of consecutive layers with the same geometry ----------------------
+    int32_t l0 = 0;
+    while (l0 < n_layers) {
+        int32_t l1 = l0 + 1;
+        const dctfp_layer& g = layers[l0];
+        while (l1 < n_layers && layers[l1].n_cols == g.n_cols && layers[l1].dtype == g.dtype && layers[l1].ld == g.ld &&
+               layers[l1].n_keep == g.n_keep && layers[l1].m_keep == g.m_keep)
+            ++l1;
+        const int ng = l1 - l0;
+        const int n = g.n_keep, m = g.m_keep, nk = n - 1;
+        const int64_t n_jobs = (int64_t)ng * n_domains;
+        const size_t esz = g.dtype == DCTFP_F32 ? 4 : 8;
+
+        // staging layout
+        const size_t off_jobb = 0;
+        const size_t off_joba = align_up(off_jobb + (size_t)n_jobs * sizeof(JobB), 16);
+        const size_t off_piece = align_up(off_joba + (size_t)n_jobs * sizeof(JobA), 16);
+        const size_t off_lens = align_up(off_piece + (size_t)ng * n_pieces * sizeof(PieceA), 16);
+        Staging& stg = ctx->staging[ctx->flip];
+        DevBuf& tab = ctx->tables[ctx->flip];
+        ctx->flip ^= 1;
+        // unique lengths (at most n_domains)
+        const size_t max_bytes = align_up(off_lens + 2 * (size_t)n_domains * sizeof(uint32_t), 16);
+        int rc = stg.ensure(max_bytes);
+        if (rc) return rc;
+        char* h = (char*)stg.p;
+        JobB* hjb = (JobB*)(h + off_jobb);
+        JobA* hja = (JobA*)(h + off_joba);
+        PieceA* hpc = (PieceA*)(h + off_piece);
+        uint32_t* hlens = (uint32_t*)(h + off_lens);
+
+        const bool trivial = (n == 1 || m == 1);  // single resampled value -> 0/0 -> 0
+        std::unordered_map<uint32_t, uint32_t> len_off;
+        std::vector<uint32_t> ulen, uoff;
+        uint64_t basis_doubles = 0;
+        if (!trivial) {
+            for (int64_t d = 0; d < n_domains; ++d) {
+                if (len_off.find(dom_len[d]) == len_off.end()) {
+                    if (basis_doubles + (uint64_t)dom_len[d] * nk > 0xffffffffu)
+                        return fail(DCTFP_ERR_LIMIT, "cosine tables of one call exceed 2^32 entries");
+                    len_off.emplace(dom_len[d], (uint32_t)basis_doubles);
+                    ulen.push_back(dom_len[d]);
+                    uoff.push_back((uint32_t)basis_doubles);
+                    basis_doubles += (uint64_t)dom_len[d] * nk;
+                }
+            }
+        }
+        const size_t nu = ulen.size();
+        uint32_t* hoffs = hlens + nu;
+        for (size_t i = 0; i < nu; ++i) {
+            hlens[i] = ulen[i];
+            hoffs[i] = uoff[i];
+        }
+        bool vec_ok = true;
+        for (int li = 0; li < ng; ++li) {
+            const dctfp_layer& ly = layers[l0 + li];
+            for (int64_t d = 0; d < n_domains; ++d) {
+                const int64_t job = (int64_t)li * n_domains + d;
+                hjb[job].out_off = d * out_stride + ly.out_offset;
+                hja[job].piece_begin = (uint32_t)((int64_t)li * n_pieces + dom_first[d]);
+                hja[job].n_pieces = dom_np[d];
+                hja[job].n_rows = dom_len[d];
+                hja[job].basis_off = trivial ? 0u : len_off[dom_len[d]];
+            }
+            uint32_t t0 = 0;
+            int32_t prev_dom = -1;
+            for (int64_t i = 0; i < n_pieces; ++i) {
+                const dctfp_piece& pc = pieces[i];
+                if (pc.domain != prev_dom) t0 = 0;
+                prev_dom = pc.domain;
+                PieceA& o = hpc[(int64_t)li * n_pieces + i];
+                o.ptr = (const char*)ly.seq_data[pc.seq] + (size_t)pc.row_start * (size_t)ly.ld * esz;
+                o.n_rows = (uint32_t)pc.n_rows;
+                o.t0 = t0;
+                t0 += (uint32_t)pc.n_rows;
+            }
+            for (int32_t s = 0; s < n_seq; ++s)
+                if (seq_rows[s] > 0 && !aligned16(ly.seq_data[s])) vec_ok = false;
+        }
+        const int vec_want = g.dtype == DCTFP_F32 ? 4 : 2;
+        if (((size_t)g.ld * esz) % 16 != 0 || g.n_cols % vec_want != 0) vec_ok = false;
+        const int vec = vec_ok ? vec_want : 1;
+
+        const size_t tab_bytes = align_up(off_lens + 2 * nu * sizeof(uint32_t), 16);
+        const size_t off_basis = align_up(tab_bytes, 256);
+        rc = tab.ensure(off_basis + (size_t)basis_doubles * sizeof(double));
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(tab.p, stg.p, tab_bytes, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(stg.ev, stream));
+        stg.pending = true;
+        char* dt = (char*)tab.p;
+        const JobB* djb = (const JobB*)(dt + off_jobb);
+        const JobA* dja = (const JobA*)(dt + off_joba);
+        const PieceA* dpc = (const PieceA*)(dt + off_piece);
+        const uint32_t* dlens = (const uint32_t*)(dt + off_lens);
+        const uint32_t* doffs = dlens + nu;
+        double* dbasis = (double*)(dt + off_basis);
+
+        if (trivial) {
+            const int64_t total = n_jobs * n * m;
+            const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+            hipLaunchKernelGGL(fill_zero_kernel, dim3(grid), dim3(256), 0, stream, djb, n_jobs, n * m, out);
+            HIP_TRY(hipGetLastError());
+            l0 = l1;
+            continue;
+        }
+
+        StEntry* st = nullptr;
+        rc = get_st(ctx, g.n_cols, m, stream, &st);
+        if (rc) return rc;
+        const int ldy = st->ldy;
+
+        {
+            uint32_t max_len = 0;
+            for (size_t i = 0; i < nu; ++i) max_len = std::max(max_len, ulen[i]);
+            const unsigned gx = (unsigned)std::min<uint64_t>(((uint64_t)max_len * nk + 255) / 256, 1024);
+            hipLaunchKernelGGL(basis_kernel, dim3(gx, (unsigned)nu), dim3(256), 0, stream, dlens, doffs, nk, dbasis);
+            HIP_TRY(hipGetLastError());
+        }
+
+        // jobs per chunk, bounded by the scratch cap and by the 2^31 grid limit
+        const size_t job_bytes = (size_t)n * ldy * sizeof(double);
+        const int n_slabs = (ldy + 64 * vec - 1) / (64 * vec);
+        int64_t chunk = std::max<int64_t>(1, (int64_t)(((size_t)ctx->opt_ws_mb << 20) / job_bytes));
+        chunk = std::min<int64_t>(chunk, (int64_t)0x7fffffff / n_slabs);
+        chunk = std::min<int64_t>(chunk, n_jobs);
+        rc = ctx->ws.ensure((size_t)chunk * job_bytes);
+        if (rc) return rc;
+        double* yprime = (double*)ctx->ws.p;
+
+        for (int64_t j0 = 0; j0 < n_jobs; j0 += chunk) {
+            const int64_t jn = std::min<int64_t>(chunk, n_jobs - j0);
+            AParams ap;
+            ap.jobs = dja + j0;
+            ap.pieces = dpc;
+            ap.basis = dbasis;
+            ap.yprime = yprime;
+            ap.n_cols = g.n_cols;
+            ap.ld = g.ld;
+            ap.ldy = ldy;
+            ap.n_slabs = n_slabs;
+            ap.grid = (unsigned)(jn * n_slabs);
+            ap.stream = stream;
+            EventPair* ep = nullptr;
+            rc = prof_begin(ctx, 0, stream, &ep);
+            if (rc) return rc;
+            launch_a(ap, g.dtype, vec, n, (int)ctx->opt_a_waves, (int)ctx->opt_a_unroll);
+            HIP_TRY(hipGetLastError());
+            rc = prof_end(ep, stream);
+            if (rc) return rc;
+
+            rc = prof_begin(ctx, 1, stream, &ep);
+            if (rc) return rc;
+            if (ctx->opt_stage_b == 1) {
+                const int64_t rows = jn * n;
+                launch_b_mfma(st->cp / 16, (unsigned)((rows + 63) / 64), stream, yprime, rows, ldy, st->dev, djb + j0, n, m, out);
+            } else {
+                hipLaunchKernelGGL(stage_b_valu_kernel, dim3((unsigned)jn), dim3(256), 0, stream, yprime, ldy, g.n_cols,
+                                   st->dev, st->cp, djb + j0, n, m, out);
+            }
+            HIP_TRY(hipGetLastError());
+            rc = prof_end(ep, stream);
+            if (rc) return rc;
+        }
+        l0 = l1;
+    }
+    return DCTFP_OK;
+}
+
+int dctfp_idct_quant(dctfp_ctx* ctx, const void* vec, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
+                     int32_t num, double* scaled_out, double* coef_out, void* stream_v) {
+    if (!ctx || !vec) return fail(DCTFP_ERR_INVALID, "dctfp_idct_quant: NULL argument");
+    if (dtype != DCTFP_F32 && dtype != DCTFP_F64) return fail(DCTFP_ERR_INVALID, "dctfp_idct_quant: dtype %d", dtype);
+    if (n_rows < 1 || n_cols < 1 || ld < n_cols || num < 1) return fail(DCTFP_ERR_INVALID, "dctfp_idct_quant: bad shape");
+    if (num > n_rows) return fail(DCTFP_ERR_SHAPE, "dctfp_idct_quant: num %d > %lld rows", num, (long long)n_rows);
+    if (num > 65535) return fail(DCTFP_ERR_LIMIT, "dctfp_idct_quant: num %d", num);
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ctx->scratch.ensure((size_t)num * n_cols * sizeof(double));
+    if (rc) return rc;
+    double* fs = (double*)ctx->scratch.p;
+    dim3 grid((unsigned)((n_cols + 63) / 64), (unsigned)num);
+    if (dtype == DCTFP_F32)
+        hipLaunchKernelGGL((generic_forward_kernel<float>), grid, dim3(64), 0, stream, (const float*)vec, n_rows, n_cols, ld, num, fs, coef_out);
+    else
+        hipLaunchKernelGGL((generic_forward_kernel<double>), grid, dim3(64), 0, stream, (const double*)vec, n_rows, n_cols, ld, num, fs, coef_out);
+    HIP_TRY(hipGetLastError());
+    if (scaled_out) {
+        hipLaunchKernelGGL(generic_inverse_kernel, dim3((unsigned)((n_cols + 63) / 64)), dim3(64), 0, stream, fs, n_cols, num, scaled_out);
+        HIP_TRY(hipGetLastError());
+    }
+    return DCTFP_OK;
+}
+
+int dctfp_scale(dctfp_ctx* ctx, const double* vec, int64_t n, double* out, void* stream_v) {
+    if (!ctx || !vec || !out) return fail(DCTFP_ERR_INVALID, "dctfp_scale: NULL argument");
+    if (n < 1) return fail(DCTFP_ERR_INVALID, "dctfp_scale: empty vector");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_v, vec, n, out);
+    HIP_TRY(hipGetLastError());
+    return DCTFP_OK;
+}
+
+int dctfp_gather_rows(dctfp_ctx* ctx, const void* embed, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
+                      const dctfp_piece* pieces, int64_t n_pieces, double* out, void* stream_v) {
+    if (!ctx || !embed || !pieces || !out) return fail(DCTFP_ERR_INVALID, "dctfp_gather_rows: NULL argument");
+    if (dtype != DCTFP_F32 && dtype != DCTFP_F64) return fail(DCTFP_ERR_INVALID, "dctfp_gather_rows: dtype %d", dtype);
+    if (n_pieces < 1 || n_pieces > 65535 || n_cols < 1 || ld < n_cols) return fail(DCTFP_ERR_INVALID, "dctfp_gather_rows: bad shape");
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t esz = dtype == DCTFP_F32 ? 4 : 8;
+    Staging& stg = ctx->staging[ctx->flip];
+    DevBuf& tab = ctx->tables[ctx->flip];
+    ctx->flip ^= 1;
+    int rc = stg.ensure((size_t)n_pieces * sizeof(PieceA));
+    if (rc) return rc;
+    PieceA* h = (PieceA*)stg.p;
+    uint64_t t0 = 0;
+    uint32_t max_rows = 0;
+    for (int64_t i = 0; i < n_pieces; ++i) {
+        const dctfp_piece& pc = pieces[i];
+        if (pc.n_rows <= 0 || pc.row_start < 0 || pc.row_start + pc.n_rows > n_rows)
+            return fail(DCTFP_ERR_INVALID, "dctfp_gather_rows: piece %lld outside the matrix", (long long)i);
+        h[i].ptr = (const char*)embed + (size_t)pc.row_start * (size_t)ld * esz;
+        h[i].n_rows = (uint32_t)pc.n_rows;
+        h[i].t0 = (uint32_t)t0;
+        t0 += (uint64_t)pc.n_rows;
+        max_rows = std::max(max_rows, (uint32_t)pc.n_rows);
+        if (t0 > 0x7fffffffu) return fail(DCTFP_ERR_LIMIT, "dctfp_gather_rows: more than 2^31 rows");
+    }
+    rc = tab.ensure((size_t)n_pieces * sizeof(PieceA));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(tab.p, stg.p, (size_t)n_pieces * sizeof(PieceA), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(stg.ev, stream));
+    stg.pending = true;
+    const unsigned gx = (unsigned)std::min<int64_t>(((int64_t)max_rows * n_cols + 255) / 256, 2048);
+    if (dtype == DCTFP_F32)
+        hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(gx, (unsigned)n_pieces), dim3(256), 0, stream, (const PieceA*)tab.p, (int)n_pieces, n_cols, ld, out);
+    else
+        hipLaunchKernelGGL((gather_rows_kernel<double>), dim3(gx, (unsigned)n_pieces), dim3(256), 0, stream, (const PieceA*)tab.p, (int)n_pieces, n_cols, ld, out);
+    HIP_TRY(hipGetLastError());
+    return DCTFP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,480 @@
+// Device code of libdctfp.so (gfx950 only).  See DESIGN.md for the data layout and
+// the roofline of each kernel.  Math reference: mgtools/DCTdomain
+// src/fingerprint.py:126-142 (idct_quant), :110-123 (scale), :194-195 (int8 cast).
+//
+// With C_N[k,t] = s_k cos(pi k (2t+1) / (2N)) (scipy DCT-II, norm='ortho'),
+// idct_quant(., K) along an axis of length N is   y = C_K^T . C_N[:K] . x   followed by
+// a min-max scale of the K resampled values.  The scale removes the k = 0 term
+// (a per-vector constant) and every common positive factor (s_k is the same for all
+// k >= 1), so the kernels accumulate only
+//     F_k = sum_t cos(pi k (2t+1) / (2N)) * (x_t - x_0),   k = 1 .. K-1
+// in float64 and resample with the bare cosines.  Subtracting x_0 is exact in float64
+// for float32 data of similar magnitude and makes a constant vector give exactly
+// F_k = 0 -> 0/0 = NaN, as the reference's FFT does.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dctfp {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct JobA {              // one (layer, domain) matrix of stage A
+    uint32_t piece_begin;  // first PieceA of this job
+    uint32_t n_pieces;
+    uint32_t n_rows;       // L_d
+    uint32_t basis_off;    // offset (doubles) of this length's cosine table
+};
+
+struct PieceA {
+    const void* ptr;  // first element of the piece's first row
+    uint32_t n_rows;
+    uint32_t t0;      // position of the piece's first row inside the domain matrix
+};
+
+struct JobB {
+    int64_t out_off;  // byte offset of this (layer, domain) block in the int8 output
+};
+
+template <int N>
+struct InvTab {  // c[j * (N-1) + k-1] = cos(pi k (2j+1) / (2N)), j < N, 1 <= k < N
+    double c[N > 1 ? N * (N - 1) : 1];
+};
+
+// cos(pi * p / q) with the argument reduced exactly in integers (q > 0, p >= 0).
+__device__ inline double cospi_ratio(uint64_t p, uint64_t q) {
+    p %= 2 * q;
+    if (p > q) p = 2 * q - p;
+    double sign = 1.0;
+    if (2 * p > q) {
+        p = q - p;
+        sign = -1.0;
+    }
+    double r = (4 * p > q) ? sinpi((double)(q - 2 * p) / (double)(2 * q)) : cospi((double)p / (double)q);
+    return sign * r;
+}
+
+// ---------------------------------------------------------------------------
+// K0: cosine tables for stage A.  Table of length L at basis[off .. off + L*NK):
+//     basis[off + t*NK + (k-1)] = cos(pi k (2t+1) / (2L))
+// ---------------------------------------------------------------------------
+__global__ void basis_kernel(const uint32_t* __restrict__ lens, const uint32_t* __restrict__ offs, int nk,
+                             double* __restrict__ basis) {
+    const uint32_t len = lens[blockIdx.y];
+    const uint32_t off = offs[blockIdx.y];
+    const uint64_t total = (uint64_t)len * nk;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t t = i / nk;
+        const uint64_t k = i % nk + 1;
+        basis[off + i] = cospi_ratio(k * (2 * t + 1), 2 * (uint64_t)len);
+    }
+}
+
+// Raw (unconverted) register image of one row segment, so that UNROLL loads can be in
+// flight before the first conversion.
+template <typename T, int VEC>
+struct Raw;
+template <>
+struct Raw<float, 4> { typedef v4f type; };
+template <>
+struct Raw<float, 1> { typedef float type; };
+template <>
+struct Raw<double, 2> { typedef v2d type; };
+template <>
+struct Raw<double, 1> { typedef double type; };
+
+// Streaming load: global address space (global_load_*, counted vmcnt waits) + nt policy.
+template <typename T, int VEC>
+__device__ inline typename Raw<T, VEC>::type load_raw(const T* p) {
+    typedef typename Raw<T, VEC>::type R;
+    typedef const R __attribute__((address_space(1))) * GP;
+    return __builtin_nontemporal_load((GP)(uintptr_t)p);
+}
+template <int VEC, typename R>
+__device__ inline double raw_elem(const R& r, int v) {
+    if constexpr (VEC == 1) return (double)r;
+    else return (double)r[v];
+}
+
+// ---------------------------------------------------------------------------
+// K1: stage A -- HBM-streaming L-axis contraction + per-channel min-max scale.
+//   grid  : n_jobs * n_slabs workgroups; workgroup = (job, slab of 64*VEC channels)
+//   block : WAVES waves; wave w streams rows w, w+WAVES, ... of every piece of the job,
+//           UNROLL rows (UNROLL x 16 B per lane) in flight; the cosines of a row are
+//           wave-uniform and come through the scalar cache (s_load) into SGPR operands.
+//   out   : yprime[(job*N + j) * ldy + col]  float64, j < N (padding columns = 0)
+// ---------------------------------------------------------------------------
+template <typename T, int N, int VEC, int WAVES, int UNROLL>
+__global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restrict__ jobs,
+                                                              const PieceA* __restrict__ pieces,
+                                                              const double* __restrict__ basis,
+                                                              double* __restrict__ yprime, int n_cols, int64_t ld,
+                                                              int ldy, int n_slabs, InvTab<N> inv) {
+    constexpr int NK = N - 1;
+    __shared__ double red[WAVES][NK * VEC][64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t job_id = blockIdx.x / (uint32_t)n_slabs;
+    const int slab = (int)(blockIdx.x % (uint32_t)n_slabs);
+    const JobA job = jobs[job_id];
+    const int col0 = (slab * 64 + lane) * VEC;
+    const int colc = (col0 < n_cols) ? col0 : 0;  // out-of-range lanes stream column 0 and are discarded
+    const PieceA* __restrict__ pc = pieces + job.piece_begin;
+    const double* __restrict__ bt = basis + job.basis_off;
+
+    double acc[NK][VEC];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[k][v] = 0.0;
+
+    double ref[VEC];
+    {
+        auto r0 = load_raw<T, VEC>(reinterpret_cast<const T*>(pc[0].ptr) + colc);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ref[v] = raw_elem<VEC>(r0, v);
+    }
+
+    for (uint32_t p = 0; p < job.n_pieces; ++p) {
+        const PieceA piece = pc[p];
+        const T* __restrict__ base = reinterpret_cast<const T*>(piece.ptr) + colc;
+        const double* __restrict__ btp = bt + (size_t)piece.t0 * NK;
+        uint32_t r = (uint32_t)wave;
+        for (; r + (UNROLL - 1) * WAVES < piece.n_rows; r += UNROLL * WAVES) {
+            typename Raw<T, VEC>::type xv[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) xv[u] = load_raw<T, VEC>(base + (size_t)(r + u * WAVES) * ld);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const double* __restrict__ c = btp + (size_t)(r + u * WAVES) * NK;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const double d = raw_elem<VEC>(xv[u], v) - ref[v];
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) acc[k][v] = fma(c[k], d, acc[k][v]);
+                }
+            }
+        }
+        for (; r < piece.n_rows; r += WAVES) {
+            auto x1 = load_raw<T, VEC>(base + (size_t)r * ld);
+            const double* __restrict__ c = btp + (size_t)r * NK;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const double d = raw_elem<VEC>(x1, v) - ref[v];
+#pragma unroll
+                for (int k = 0; k < NK; ++k) acc[k][v] = fma(c[k], d, acc[k][v]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[wave][k * VEC + v][lane] = acc[k][v];
+    __syncthreads();
+
+    // combine the waves in a fixed order, resample to N points, min-max scale (scale():
+    // src/fingerprint.py:110-123, applied per channel at :139-140), store Y'.
+    for (int cl = threadIdx.x; cl < 64 * VEC; cl += WAVES * 64) {
+        const int ln = cl / VEC, v = cl % VEC;
+        const int col = slab * 64 * VEC + cl;
+        if (col >= ldy) continue;
+        double f[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            double s = red[0][k * VEC + v][ln];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) s += red[w][k * VEC + v][ln];
+            f[k] = s;
+        }
+        double y[N];
+        double mn = INFINITY, mx = -INFINITY;
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) s = fma(inv.c[j * NK + k], f[k], s);
+            y[j] = s;
+            bad |= (s != s);
+            mn = fmin(mn, s);
+            mx = fmax(mx, s);
+        }
+        const double den = mx - mn;
+        double* __restrict__ o = yprime + (size_t)job_id * N * ldy + col;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double z = bad ? __builtin_nan("") : (y[j] - mn) / den;
+            if (col >= n_cols) z = 0.0;
+            o[(size_t)j * ldy] = z;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Shared epilogue helper: trunc(127 z) with NaN / out-of-range -> 0
+// ((ddct*127).astype('int8'), src/fingerprint.py:195; x86 numpy gives 0 for NaN).
+// ---------------------------------------------------------------------------
+__device__ inline int8_t quant127(double num, double den, bool bad) {
+    const double v = (num / den) * 127.0;
+    return (!bad && v >= 0.0 && v <= 127.0) ? (int8_t)(int)v : (int8_t)0;
+}
+
+// ---------------------------------------------------------------------------
+// K2 (MFMA): stage B -- rows (job, j) x K = D contraction against St (D x m), then per-row
+// min-max scale and int8 truncation.  v_mfma_f64_16x16x4_f64; workgroup = 4 waves x 16 rows,
+// all NT column tiles per wave; St staged through LDS in 32-row chunks (row stride CP+4
+// doubles keeps the four k-groups of a ds_read_b64 on distinct banks).
+//   f64 MFMA layouts (cdna_hip_programming.md section 3): A[i = l&15][k = l>>4],
+//   B[k = l>>4][j = l&15], C/D reg i: row = (l>>4) + 4 i, col = l & 15.
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void stage_b_mfma_kernel(const double* __restrict__ yp, int64_t n_rows_total,
+                                                            int ldy, const double* __restrict__ st,
+                                                            const JobB* __restrict__ jobs, int n, int m,
+                                                            int8_t* __restrict__ out) {
+    constexpr int CP = NT * 16;
+    constexpr int LDS_LD = CP + 4;
+    constexpr int KB = 32;
+    __shared__ double bs[KB][LDS_LD];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    int64_t arow = row0 + r16;
+    if (arow >= n_rows_total) arow = n_rows_total - 1;
+    const double* __restrict__ ap = yp + (size_t)arow * ldy + 4 * g;
+
+    v4d acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    for (int kb = 0; kb < ldy; kb += KB) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < KB * CP / 2; i += 256) {
+            const int kk = i / (CP / 2);
+            const int cc = (i % (CP / 2)) * 2;
+            const v2d v = *reinterpret_cast<const v2d*>(st + (size_t)(kb + kk) * CP + cc);
+            bs[kk][cc] = v[0];
+            bs[kk][cc + 1] = v[1];
+        }
+        __syncthreads();
+        const v4d a0 = *reinterpret_cast<const v4d*>(ap + kb);
+        const v4d a1 = *reinterpret_cast<const v4d*>(ap + kb + 16);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double a = q ? a1[r] : a0[r];
+                const int kk = q * 16 + 4 * g + r;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bs[kk][t * 16 + r16], acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t grow = row0 + g + 4 * i;
+        double mn = INFINITY, mx = -INFINITY;
+        int bad = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 16 + r16;
+            if (col < m) {
+                const double v = acc[t][i];
+                bad |= (v != v) ? 1 : 0;
+                mn = fmin(mn, v);
+                mx = fmax(mx, v);
+            }
+        }
+#pragma unroll
+        for (int s = 1; s < 16; s <<= 1) {
+            mn = fmin(mn, __shfl_xor(mn, s));
+            mx = fmax(mx, __shfl_xor(mx, s));
+            bad |= __shfl_xor(bad, s);
+        }
+        if (grow < n_rows_total) {
+            const int64_t job = grow / n;
+            const int j = (int)(grow - job * n);
+            int8_t* __restrict__ o = out + jobs[job].out_off + (int64_t)j * m;
+            const double den = mx - mn;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = t * 16 + r16;
+                if (col < m) o[col] = quant127(acc[t][i] - mn, den, bad != 0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2 (VALU): same result as the MFMA kernel, one workgroup per job, plain FMAs.
+// Kept as the cross-check of the MFMA fragment layout and for A/B timing.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stage_b_valu_kernel(const double* __restrict__ yp, int ldy, int n_cols,
+                                                            const double* __restrict__ st, int cp,
+                                                            const JobB* __restrict__ jobs, int n, int m,
+                                                            int8_t* __restrict__ out) {
+    constexpr int DCH = 256;  // channels staged per pass
+    __shared__ double ys[DCTFP_MAX_N_K][DCH];
+    __shared__ double bl[DCTFP_MAX_N_K * DCTFP_MAX_M_K];
+    const int job = blockIdx.x;
+    const double* __restrict__ yj = yp + (size_t)job * n * ldy;
+    const int n_out = n * m;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int d0 = 0; d0 < n_cols; d0 += DCH) {
+        const int dn = min(DCH, n_cols - d0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n * DCH; i += 256) {
+            const int j = i / DCH, d = i % DCH;
+            ys[j][d] = (d < dn) ? yj[(size_t)j * ldy + d0 + d] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int o = threadIdx.x + s * 256;
+            if (o < n_out) {
+                const int j = o / m, c = o % m;
+                double a = acc[s];
+                for (int d = 0; d < dn; ++d) a = fma(ys[j][d], st[(size_t)(d0 + d) * cp + c], a);
+                acc[s] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int o = threadIdx.x + s * 256;
+        if (o < n_out) bl[o] = acc[s];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < n; j += 4) {
+        double mn = INFINITY, mx = -INFINITY;
+        int bad = 0;
+        for (int c = lane; c < m; c += 64) {
+            const double v = bl[j * m + c];
+            bad |= (v != v) ? 1 : 0;
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+        }
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            mn = fmin(mn, __shfl_xor(mn, s));
+            mx = fmax(mx, __shfl_xor(mx, s));
+            bad |= __shfl_xor(bad, s);
+        }
+        int8_t* __restrict__ o = out + jobs[job].out_off + (int64_t)j * m;
+        const double den = mx - mn;
+        for (int c = lane; c < m; c += 64) o[c] = quant127(bl[j * m + c] - mn, den, bad != 0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Zero fill of (layer, domain) blocks whose n or m is 1: the single resampled value
+// scales to 0/0 = NaN -> 0 (golden case qdim_n1).
+// ---------------------------------------------------------------------------
+__global__ void fill_zero_kernel(const JobB* __restrict__ jobs, int64_t n_jobs, int block_bytes,
+                                 int8_t* __restrict__ out) {
+    const int64_t total = n_jobs * block_bytes;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[jobs[i / block_bytes].out_off + i % block_bytes] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// Generic (any num) idct_quant pieces -- NOT a hot path; backs dctfp_idct_quant.
+//   G1: fs[k][c] = sum_t cos(pi k (2t+1)/(2N)) (x[t][c] - x[0][c])  (k >= 1);  fs[0][c] = sum_t x[t][c]
+//       coef[c][k] = s_k * (k ? fs[k][c] : fs[0][c])
+//   G2: y_j = sum_{k>=1} cos(pi k (2j+1)/(2 num)) fs[k][c], min-max scaled over j.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void generic_forward_kernel(const T* __restrict__ x, int64_t n_rows, int64_t n_cols, int64_t ld, int num,
+                                       double* __restrict__ fs, double* __restrict__ coef) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (c >= n_cols) return;
+    const double x0 = (double)x[c];
+    double s = 0.0;
+    if (k == 0) {
+        for (int64_t t = 0; t < n_rows; ++t) s += (double)x[t * ld + c];
+    } else {
+        for (int64_t t = 0; t < n_rows; ++t)
+            s = fma(cospi_ratio((uint64_t)k * (2 * (uint64_t)t + 1), 2 * (uint64_t)n_rows), (double)x[t * ld + c] - x0, s);
+    }
+    fs[(size_t)k * n_cols + c] = s;
+    if (coef) coef[(size_t)c * num + k] = s * (k == 0 ? sqrt(1.0 / (double)n_rows) : sqrt(2.0 / (double)n_rows));
+}
+
+__global__ void generic_inverse_kernel(const double* __restrict__ fs, int64_t n_cols, int num,
+                                       double* __restrict__ scaled) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cols) return;
+    double mn = INFINITY, mx = -INFINITY;
+    bool bad = false;
+    for (int j = 0; j < num; ++j) {
+        double s = 0.0;
+        for (int k = 1; k < num; ++k)
+            s = fma(cospi_ratio((uint64_t)k * (2 * (uint64_t)j + 1), 2 * (uint64_t)num), fs[(size_t)k * n_cols + c], s);
+        scaled[(size_t)j * n_cols + c] = s;
+        bad |= (s != s);
+        mn = fmin(mn, s);
+        mx = fmax(mx, s);
+    }
+    const double den = mx - mn;
+    for (int j = 0; j < num; ++j) {
+        const double s = scaled[(size_t)j * n_cols + c];
+        scaled[(size_t)j * n_cols + c] = bad ? __builtin_nan("") : (s - mn) / den;
+    }
+}
+
+// scale(): one workgroup, any length.
+__global__ __launch_bounds__(256) void scale_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ out) {
+    __shared__ double smn[4], smx[4];
+    __shared__ int sbad[4];
+    double mn = INFINITY, mx = -INFINITY;
+    int bad = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const double x = v[i];
+        bad |= (x != x) ? 1 : 0;
+        mn = fmin(mn, x);
+        mx = fmax(mx, x);
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        mn = fmin(mn, __shfl_xor(mn, s));
+        mx = fmax(mx, __shfl_xor(mx, s));
+        bad |= __shfl_xor(bad, s);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        smn[threadIdx.x >> 6] = mn;
+        smx[threadIdx.x >> 6] = mx;
+        sbad[threadIdx.x >> 6] = bad;
+    }
+    __syncthreads();
+    mn = fmin(fmin(smn[0], smn[1]), fmin(smn[2], smn[3]));
+    mx = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
+    bad = sbad[0] | sbad[1] | sbad[2] | sbad[3];
+    const double den = mx - mn;
+    for (int64_t i = threadIdx.x; i < n; i += 256) out[i] = bad ? __builtin_nan("") : (v[i] - mn) / den;
+}
+
+// get_doms row gather + float64 promotion; one PieceA per piece, t0 = destination row.
+template <typename T>
+__global__ void gather_rows_kernel(const PieceA* __restrict__ pieces, int n_pieces, int64_t n_cols, int64_t ld,
+                                   double* __restrict__ out) {
+    const PieceA pc = pieces[blockIdx.y];
+    const T* __restrict__ src = reinterpret_cast<const T*>(pc.ptr);
+    const int64_t total = (int64_t)pc.n_rows * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n_cols, c = i % n_cols;
+        out[((int64_t)pc.t0 + r) * n_cols + c] = (double)src[r * ld + c];
+    }
+}
+
+}  // namespace dctfp

@@ -1,0 +1,210 @@
+"""``Fingerprint`` -- drop-in for mgtools/DCTdomain's ``src/fingerprint.py`` class
+(:17-201) with the iDCT quantisation running on MI355X HIP kernels.
+
+Same fields, same methods, same results:
+
+* ``quantize(qdim)``     src/fingerprint.py:174-201  -> ``dctfp_quantize``   (hot path)
+* ``idct_quant(vec, n)`` src/fingerprint.py:126-142  -> ``dctfp_idct_quant``
+* ``scale(vec)``         src/fingerprint.py:110-123  -> ``dctfp_scale``
+* ``get_doms(emb, dom)`` src/fingerprint.py:145-171  -> ``dctfp_gather_rows`` (+ host string rules)
+* ``writece`` / ``reccut`` src/fingerprint.py:45-107 -> see ``dctdomain_amd.reccut``
+
+``embed`` values may be numpy arrays (as in the reference; copied to the GPU once) or
+torch tensors already on the GPU straight from the ESM-2 forward pass (new).  There is no
+CPU implementation behind this class: without libdctfp.so and a GPU it raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+from .batch import LayerBatch, PieceTable, quantize_batch
+from .domains import split_domain
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('dctdomain_amd needs an MI355X GPU (torch.cuda.is_available() is False); '
+                           'there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _to_device_matrix(x, device=None) -> torch.Tensor:
+    """numpy / torch 2-D matrix -> contiguous float32 or float64 tensor on the GPU.
+    Every dtype the reference accepts is promoted exactly (it computes in float64)."""
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        a = np.asarray(x)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float32 if a.dtype in (np.float16,) else np.float64)
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    if t.dim() != 2:
+        raise ValueError(f'expected a 2-D matrix, got shape {tuple(t.shape)}')
+    if t.dtype in (torch.float16, torch.bfloat16):
+        t = t.to(torch.float32)
+    elif t.dtype not in (torch.float32, torch.float64):
+        t = t.to(torch.float64)
+    if t.device.type != 'cuda':
+        t = t.to(device if device is not None else _device())
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _like_input(result: torch.Tensor, like):
+    """numpy in -> numpy out (the reference's types); tensor in -> tensor out."""
+    if isinstance(like, torch.Tensor):
+        return result
+    return result.cpu().numpy()
+
+
+@dataclass
+class Fingerprint:
+    """Carrier of one protein: embeddings, contact map, predicted domains and their
+    int8 fingerprints.  Attributes as in the reference (src/fingerprint.py:30-35)."""
+    pid: str = field(default_factory=str)
+    seq: str = field(default_factory=str)
+    embed: dict = field(default_factory=dict)
+    contacts: np.array = field(default_factory=list)
+    domains: list = field(default_factory=list)
+    quants: dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        if not isinstance(self.contacts, torch.Tensor):
+            self.contacts = np.array(self.contacts)
+
+    # -- domain prediction (src/fingerprint.py:45-107) ---------------------------------
+    def writece(self, outfile: str, t: float):
+        from .reccut import write_ce
+        write_ce(self, outfile, t)
+
+    def reccut(self, threshold: float):
+        from .reccut import predict_domains
+        domains = predict_domains(self, threshold)
+        for dom in domains:
+            self.domains.append(dom)
+        if len(domains) > 1:
+            self.domains.append(f'1-{len(self.seq)}')
+
+    # -- helpers of quantize -------------------------------------------------------------
+    def scale(self, vec):
+        """(vec - min) / (max - min); max == min gives NaN (src/fingerprint.py:110-123)."""
+        if isinstance(vec, torch.Tensor):
+            t = vec.to(torch.float64)
+            if t.device.type != 'cuda':
+                t = t.to(_device())
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(vec, dtype=np.float64))).to(_device())
+        t = t.contiguous()
+        flat = t.reshape(-1)
+        out = torch.empty_like(flat)
+        ctx = _lib.get_context(t.device.index)
+        stream = torch.cuda.current_stream(t.device)
+        _lib.check(ctx._lib.dctfp_scale(ctx.handle, flat.data_ptr(), flat.numel(), out.data_ptr(),
+                                        C.c_void_p(stream.cuda_stream)))
+        return _like_input(out.reshape(t.shape), vec)
+
+    def idct_quant(self, vec, num: int):
+        """DCT-II along axis 0, keep ``num``, inverse DCT of length ``num``, min-max scale per
+        column; returns (num, n_cols) float64 (src/fingerprint.py:126-142)."""
+        t = _to_device_matrix(vec)
+        n_rows, n_cols = t.shape
+        k = min(int(num), n_rows)      # f[:, :num] cannot be wider than the transform
+        out = torch.empty((k, n_cols), dtype=torch.float64, device=t.device)
+        ctx = _lib.get_context(t.device.index)
+        stream = torch.cuda.current_stream(t.device)
+        _lib.check(ctx._lib.dctfp_idct_quant(ctx.handle, t.data_ptr(), _dtype_code(t), n_rows, n_cols,
+                                             t.stride(0) if n_rows > 1 else n_cols, k, out.data_ptr(), None,
+                                             C.c_void_p(stream.cuda_stream)))
+        return _like_input(out, vec)
+
+    def dct_coefficients(self, vec, num: int):
+        """``f[:, :num]`` of src/fingerprint.py:137 -- (n_cols, num) float64.  Not in the
+        reference's API; exposes the intermediate coefficients for parity checks."""
+        t = _to_device_matrix(vec)
+        n_rows, n_cols = t.shape
+        k = min(int(num), n_rows)
+        coef = torch.empty((n_cols, k), dtype=torch.float64, device=t.device)
+        ctx = _lib.get_context(t.device.index)
+        stream = torch.cuda.current_stream(t.device)
+        _lib.check(ctx._lib.dctfp_idct_quant(ctx.handle, t.data_ptr(), _dtype_code(t), n_rows, n_cols,
+                                             t.stride(0) if n_rows > 1 else n_cols, k, None, coef.data_ptr(),
+                                             C.c_void_p(stream.cuda_stream)))
+        return _like_input(coef, vec)
+
+    def get_doms(self, embed, dom: str) -> tuple:
+        """Rows of a (possibly discontinuous) domain as a float64 matrix + the cleaned
+        domain string (src/fingerprint.py:145-171, quirks in ``domains.split_domain``)."""
+        t = _to_device_matrix(embed)
+        n_rows, n_cols = t.shape
+        pieces, key = split_domain(dom, n_rows)
+        total = sum(n for _, n in pieces)
+        out = torch.empty((total, n_cols), dtype=torch.float64, device=t.device)
+        if total:
+            rec = np.zeros(len(pieces), dtype=_lib.PIECE_DTYPE)
+            rec['row_start'] = [p[0] for p in pieces]
+            rec['n_rows'] = [p[1] for p in pieces]
+            ctx = _lib.get_context(t.device.index)
+            stream = torch.cuda.current_stream(t.device)
+            _lib.check(ctx._lib.dctfp_gather_rows(ctx.handle, t.data_ptr(), _dtype_code(t), n_rows, n_cols,
+                                                  t.stride(0) if n_rows > 1 else n_cols, rec.ctypes.data, len(rec),
+                                                  out.data_ptr(), C.c_void_p(stream.cuda_stream)))
+        return _like_input(out, embed), key
+
+    # -- the hot path ----------------------------------------------------------------------
+    def quantize(self, qdim: list):
+        """iDCT quantisation of every domain of every layer (src/fingerprint.py:174-201).
+
+        ``qdim[2i], qdim[2i+1]`` = kept points along the sequence / channel axis of layer
+        ``i`` (dict order).  Afterwards ``quants[dom]`` is an integer array of
+        ``sum n_i*m_i`` values 0..127 and ``domains == list(quants)``.  Raises
+        ``ValueError`` where the reference's reshape does (a domain shorter than n, a layer
+        narrower than m) -- before touching ``quants``."""
+        embeds = list(self.embed.values())
+        if len(qdim) < 2 * len(embeds):
+            raise IndexError('list index out of range')      # qdim[i*2] in the reference
+        device = None
+        for e in embeds:
+            if isinstance(e, torch.Tensor) and e.device.type == 'cuda':
+                device = e.device
+                break
+        mats = [_to_device_matrix(e, device) for e in embeds]
+
+        # layers are grouped while they share the row count (one piece table per group)
+        results = []          # per layer: (table, tensor rows, column offset, n*m)
+        i = 0
+        while i < len(mats):
+            j = i
+            while j + 1 < len(mats) and mats[j + 1].shape[0] == mats[i].shape[0] \
+                    and mats[j + 1].device == mats[i].device:
+                j += 1
+            table = PieceTable([mats[i].shape[0]], [self.domains])
+            layers = [LayerBatch([mats[k]], qdim[2 * k], qdim[2 * k + 1]) for k in range(i, j + 1)]
+            out = quantize_batch(layers, table)
+            host = out.cpu().numpy() if table.n_domains else np.zeros((0, 0), np.int8)
+            off = 0
+            for k in range(i, j + 1):
+                nm = qdim[2 * k] * qdim[2 * k + 1]
+                results.append((table, host, off, nm))
+                off += nm
+            i = j + 1
+
+        for table, host, off, nm in results:                   # layer-major, then domain order
+            for row, key in enumerate(table.keys):
+                self.quants.setdefault(key, [])
+                if not isinstance(self.quants[key], list):
+                    self.quants[key] = list(self.quants[key])
+                self.quants[key].extend(host[row, off:off + nm].astype(np.int64).tolist())
+        for key, value in self.quants.items():
+            self.quants[key] = np.array(value)
+        self.domains = list(self.quants.keys())
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    return _lib.DCTFP_F32 if t.dtype == torch.float32 else _lib.DCTFP_F64

@@ -1,0 +1,137 @@
+/*
+ * dctfp.h -- C ABI of libdctfp.so: MI355X (gfx950) DCT-fingerprint kernels.
+ *
+ * Drop-in boundary for ONE path of mgtools/DCTdomain: src/fingerprint.py's
+ * Fingerprint.quantize and the helpers it calls.  The reference is pure
+ * Python (numpy + scipy.fft) and has no FFI of its own; every entry point
+ * below names the reference function (file:line, relative to the reference
+ * checkout) whose work it replaces.  The Python host side
+ * (dctdomain_amd/fingerprint.py) binds these with ctypes; INTEGRATION.md shows
+ * the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C: pointers and sizes only, no C++ or torch types;
+ *  - every function returns 0 (DCTFP_OK) or a negative DCTFP_ERR_* code; the
+ *    message of the last failure of the calling thread is dctfp_last_error();
+ *    nothing throws or longjmps across the boundary;
+ *  - "device pointer" = memory of the context's GPU; "host pointer" = ordinary
+ *    host memory that is only read during the call;
+ *  - the caller owns every buffer.  Work is enqueued on the given hipStream_t
+ *    (passed as void*; NULL = the default stream) and is stream-ordered: keep
+ *    the device buffers alive until the stream has passed the call;
+ *  - one context per (process, device); a context is used by one host thread
+ *    at a time;
+ *  - arithmetic is float64 end to end like the reference (which promotes to
+ *    float64 in get_doms, src/fingerprint.py:160,169); outputs are the
+ *    reference's truncated ints 0..127, NaN -> 0 (src/fingerprint.py:194-195).
+ */
+#ifndef DCTFP_H
+#define DCTFP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCTFP_VERSION 100 /* 0.1.0 */
+
+#define DCTFP_OK 0
+#define DCTFP_ERR_INVALID (-1) /* bad argument (null pointer, piece outside its sequence, ...) */
+#define DCTFP_ERR_SHAPE (-2)   /* a domain has fewer rows than n, or a layer fewer channels than m:
+                                  the reference's "ValueError: cannot reshape array" (src/fingerprint.py:194) */
+#define DCTFP_ERR_HIP (-3)     /* a HIP runtime call failed */
+#define DCTFP_ERR_NOMEM (-4)   /* workspace allocation failed */
+#define DCTFP_ERR_LIMIT (-5)   /* n > DCTFP_MAX_N or m > DCTFP_MAX_M */
+
+#define DCTFP_MAX_N 8   /* kept points along the sequence axis (reference: 3; PROST: 5) */
+#define DCTFP_MAX_M 128 /* kept points along the channel axis  (reference: 80; PROST: 44/85) */
+
+#define DCTFP_F32 0
+#define DCTFP_F64 1
+
+typedef struct dctfp_ctx dctfp_ctx;
+
+/* One embedding layer of a batch = one value of Fingerprint.embed (src/fingerprint.py:33,184).
+ * The rows of sequence s start at seq_data[s]; row r, channel c is seq_data[s][r * ld + c]. */
+typedef struct {
+    const void* const* seq_data; /* HOST array [n_seq] of DEVICE pointers */
+    int64_t ld;                  /* leading dimension in elements (>= n_cols) */
+    int32_t n_cols;              /* D */
+    int32_t dtype;               /* DCTFP_F32 or DCTFP_F64 */
+    int32_t n_keep;              /* n = qdim[2i]   (src/fingerprint.py:185) */
+    int32_t m_keep;              /* m = qdim[2i+1] */
+    int32_t out_offset;          /* first column of this layer's n*m block in an output row */
+    int32_t reserved;
+} dctfp_layer;
+
+/* One contiguous run of rows of a domain = one "b-e" piece of a domain string after
+ * get_doms' clean-up (src/fingerprint.py:163-169).  Pieces of one domain are consecutive
+ * in the table and in concatenation order. */
+typedef struct {
+    int64_t row_start; /* 0-based first row inside sequence `seq` */
+    int32_t n_rows;    /* > 0 */
+    int32_t domain;    /* output row index, 0 .. n_domains-1, non-decreasing over the table */
+    int32_t seq;       /* index into seq_data / seq_rows */
+    int32_t reserved;
+} dctfp_piece;
+
+int dctfp_version(void);
+const char* dctfp_last_error(void);
+
+/* Context on HIP device `device`: owns the cosine bases, job tables and the float64
+ * scratch between the two kernels.  Replaces nothing in the reference (it has no state). */
+int dctfp_create(int device, dctfp_ctx** out);
+int dctfp_destroy(dctfp_ctx* ctx);
+
+/* Fingerprint.quantize for a ragged batch (src/fingerprint.py:174-201, called by
+ * make_db.queue_cpu at src/make_db.py:30):  for every layer i and every domain d
+ *     out[d * out_stride + layers[i].out_offset + j * m + c] = trunc(127 * Z_i,d[j][c])
+ * where Z is get_doms -> idct_quant(., n) -> idct_quant(.T, m).T of that domain's rows.
+ * All layers share the piece table (same sequences, same row numbering).
+ *   layers, seq_rows, pieces : host pointers;  out : device pointer, int8.
+ *   seq_rows[s] = number of rows of sequence s (bounds check of the pieces).
+ * Errors: DCTFP_ERR_SHAPE if some domain has fewer than n rows or n_cols < m (nothing
+ * is launched in that case). */
+int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, int32_t n_seq,
+                   const int64_t* seq_rows, const dctfp_piece* pieces, int64_t n_pieces,
+                   int64_t n_domains, int8_t* out, int64_t out_stride, void* stream);
+
+/* Fingerprint.idct_quant(vec, num) for a (n_rows, n_cols) device matrix
+ * (src/fingerprint.py:126-142): DCT-II (ortho) along the rows, keep `num`, inverse DCT of
+ * length `num`, min-max scale of every column over its `num` values.
+ *   scaled_out : device float64 (num, n_cols) = the return value of idct_quant, or NULL
+ *   coef_out   : device float64 (n_cols, num) = f[:, :num] of src/fingerprint.py:137
+ *                (the "intermediate float coefficients"), or NULL
+ * Any num >= 1 (num > n_rows is DCTFP_ERR_SHAPE).  Not a hot path. */
+int dctfp_idct_quant(dctfp_ctx* ctx, const void* vec, int32_t dtype, int64_t n_rows, int64_t n_cols,
+                     int64_t ld, int32_t num, double* scaled_out, double* coef_out, void* stream);
+
+/* Fingerprint.scale(vec) (src/fingerprint.py:110-123): (v - min) / (max - min) of a
+ * device float64 vector of length n; max == min gives NaN like the reference. */
+int dctfp_scale(dctfp_ctx* ctx, const double* vec, int64_t n, double* out, void* stream);
+
+/* Row gather + float64 promotion of Fingerprint.get_doms (src/fingerprint.py:160-169) for
+ * ONE domain: the pieces (host array, rows relative to `embed`) are concatenated into
+ * out (sum n_rows, n_cols) float64, device. */
+int dctfp_gather_rows(dctfp_ctx* ctx, const void* embed, int32_t dtype, int64_t n_rows, int64_t n_cols,
+                      int64_t ld, const dctfp_piece* pieces, int64_t n_pieces, double* out, void* stream);
+
+/* Tuning / instrumentation knobs (no reference counterpart).
+ *   "stage_b"      0 = plain VALU kernel, 1 = MFMA f64 kernel (default)
+ *   "a_waves"      waves per workgroup of the stage-A kernel (4, 8 or 16)
+ *   "a_unroll"     rows in flight per wave (4 or 8)
+ *   "profile"      1 = bracket the kernels with hipEvents (see dctfp_profile)
+ *   "workspace_mb" cap of the float64 scratch between the kernels */
+int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value);
+int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value);
+
+/* With "profile" = 1: synchronises the recorded events and returns the accumulated
+ * device time (ms) and launch count of stage A ([0]) and stage B ([1]) since the last
+ * call, then resets the accumulators. */
+int dctfp_profile(dctfp_ctx* ctx, double ms[2], int64_t launches[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCTFP_H */

@@ -1,0 +1,54 @@
+"""CPU baseline worker for bench.py -- TEST/MEASUREMENT INFRASTRUCTURE, not product code.
+
+Times the *faithful* oracle form (same scipy.fft calls and per-row scale loop as the
+reference's Fingerprint.quantize, src/fingerprint.py:174-201) on the bench workload's
+shape, one process per core like the reference's multiprocessing.Pool
+(src/make_db.py:48-49).  Inputs are generated inside each worker, so no embedding is
+pickled in the timed region (which favours the CPU side relative to make_db.py)."""
+
+from __future__ import annotations
+
+import os
+import time
+
+
+def _worker(args):
+    seed, n_rows, n_cols, n_layers, qdim, seconds = args
+    os.environ['OMP_NUM_THREADS'] = '1'
+    os.environ['OPENBLAS_NUM_THREADS'] = '1'
+    import numpy as np
+    from oracle import dct_oracle as orc
+    rng = np.random.default_rng(seed)
+    pool = []
+    for _ in range(4):        # a few distinct proteins, cycled
+        layers = [(rng.standard_normal((n_rows, n_cols)) * np.exp(rng.standard_normal(n_cols))
+                   + 5 * rng.standard_normal(n_cols)).astype(np.float32) for _ in range(n_layers)]
+        pool.append(layers)
+    dom = [f'1-{n_rows}']
+    orc.quantize(pool[0], dom, qdim)          # warm-up
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        orc.quantize(pool[done % len(pool)], dom, qdim)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            return done, el
+
+
+def run(n_rows=500, n_cols=1280, n_layers=2, qdim=(3, 80, 3, 80), seconds=12.0, procs=None):
+    """Returns dict(value=fingerprints/s over all workers, cores=procs, sample=...)."""
+    import multiprocessing as mp
+    if procs is None:
+        try:
+            procs = len(os.sched_getaffinity(0))
+        except AttributeError:
+            procs = os.cpu_count() or 1
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(procs) as pool:
+        res = pool.map(_worker, [(100 + i, n_rows, n_cols, n_layers, list(qdim), seconds) for i in range(procs)])
+    total = sum(r[0] for r in res)
+    rate = sum(r[0] / r[1] for r in res)
+    return {'value': rate, 'unit': 'fingerprints/s', 'cores': procs, 'kind': 'port',
+            'sample': f'{total} fingerprints (L={n_rows}, D={n_cols}, {n_layers} layers, qdim {list(qdim)}) in '
+                      f'{seconds:.0f} s on {procs} processes; oracle faithful form (scipy.fft dct/idct + per-row scale loop)'}

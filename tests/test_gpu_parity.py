@@ -1,0 +1,265 @@
+"""GPU parity: the HIP path (through the C ABI, via dctdomain_amd) against the golden vectors
+made by the reference itself and against the oracle on seeded inputs.  int8: bit-exact."""
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import dct_oracle as orc
+from recipes import make_input
+
+pytestmark = pytest.mark.gpu
+
+ALL_OK = gu.cases(expect='ok')
+ALL_ERR = gu.cases(expect='ValueError')
+
+
+@pytest.fixture(scope='module')
+def dd():
+    import torch
+    assert torch.cuda.is_available()
+    import dctdomain_amd
+    return dctdomain_amd
+
+
+def run_fp(dd, layers, domains, qdim, as_tensor=False):
+    import torch
+    if as_tensor:
+        embed = {i: torch.from_numpy(x).cuda() for i, x in enumerate(layers)}
+    else:
+        embed = {i: x for i, x in enumerate(layers)}
+    fp = dd.Fingerprint(pid='t', seq='A' * layers[0].shape[0], embed=embed, domains=list(domains))
+    fp.quantize(list(qdim))
+    return fp
+
+
+@pytest.mark.parametrize('case', ALL_OK, ids=gu.case_ids(ALL_OK))
+def test_golden_bit_exact(dd, case):
+    layers = gu.build_layers(case)
+    fp = run_fp(dd, layers, case['domains'], case['qdim'])
+    exp = gu.expected(case)
+    assert list(fp.quants.keys()) == case['keys']
+    assert fp.domains == case['keys']
+    for k in exp:
+        assert fp.quants[k].dtype == np.int64
+        np.testing.assert_array_equal(fp.quants[k], exp[k].astype(np.int64), err_msg=f"{case['id']} {k}")
+
+
+@pytest.mark.parametrize('case', ALL_ERR, ids=gu.case_ids(ALL_ERR))
+def test_golden_errors(dd, case):
+    layers = gu.build_layers(case)
+    with pytest.raises(ValueError, match='cannot reshape array'):
+        run_fp(dd, layers, case['domains'], case['qdim'])
+
+
+SUBSET = [c for c in ALL_OK if c['id'].startswith(('two_', 'dom_', 'qdim_', 'contact', 'inline', 'deg_'))]
+
+
+@pytest.mark.parametrize('opts', [dict(stage_b=0), dict(stage_b=1), dict(a_waves=8, a_unroll=4),
+                                  dict(a_waves=16, a_unroll=8), dict(a_waves=4, a_unroll=4),
+                                  dict(workspace_mb=16)],
+                         ids=['valuB', 'mfmaB', 'w8u4', 'w16u8', 'w4u4', 'smallws'])
+def test_kernel_variants_agree_with_golden(dd, opts):
+    import torch
+    ctx = dd.get_context(torch.cuda.current_device())
+    saved = {k: ctx.get_option(k) for k in opts}
+    try:
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        for case in SUBSET:
+            layers = gu.build_layers(case)
+            fp = run_fp(dd, layers, case['domains'], case['qdim'], as_tensor=True)
+            exp = gu.expected(case)
+            assert list(fp.quants.keys()) == case['keys']
+            for k in exp:
+                np.testing.assert_array_equal(fp.quants[k], exp[k].astype(np.int64), err_msg=f"{case['id']} {k} {opts}")
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+
+
+def test_intermediates_within_tolerance(dd):
+    """North star: intermediate float coefficients within 1e-5 of the scipy reference."""
+    arr = gu.arrays()
+    checked = 0
+    for case in ALL_OK:
+        if not case.get('intermediates'):
+            continue
+        layers = gu.build_layers(case)
+        n, m = case['qdim'][0], case['qdim'][1]
+        fp = dd.Fingerprint(pid='t', seq='A' * layers[0].shape[0], embed={0: layers[0]})
+        x, key = fp.get_doms(layers[0], case['domains'][0])
+        assert x.dtype == np.float64
+        xo, ko = orc.get_doms(layers[0], case['domains'][0])
+        assert key == ko
+        np.testing.assert_array_equal(x, xo)
+        coef = fp.dct_coefficients(x, n)
+        scale = max(1.0, np.abs(arr[f"{case['id']}/coef"]).max())
+        np.testing.assert_allclose(coef, arr[f"{case['id']}/coef"], rtol=0, atol=1e-5)
+        assert np.abs(coef - arr[f"{case['id']}/coef"]).max() <= 1e-11 * scale      # what we really get
+        yp = fp.idct_quant(x, n)
+        np.testing.assert_allclose(yp, arr[f"{case['id']}/Yp"], rtol=0, atol=1e-5)
+        assert np.abs(yp - arr[f"{case['id']}/Yp"]).max() <= 1e-9
+        z = fp.idct_quant(yp.T, m).T
+        np.testing.assert_allclose(z, arr[f"{case['id']}/Z"], rtol=0, atol=1e-5)
+        assert np.abs(z - arr[f"{case['id']}/Z"]).max() <= 1e-8
+        checked += 1
+    assert checked >= 6
+
+
+def test_scale_and_get_doms_methods(dd):
+    import torch
+    rng = np.random.default_rng(5)
+    fp = dd.Fingerprint()
+    for n in (1, 3, 80, 1000, 70001):
+        v = rng.standard_normal(n)
+        got = fp.scale(v)
+        with np.errstate(all='ignore'):
+            exp = orc.scale(v)
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+        np.testing.assert_allclose(got[~np.isnan(got)], exp[~np.isnan(exp)], rtol=0, atol=0)
+    v = np.array([1.0, np.nan, 3.0])
+    assert np.isnan(fp.scale(v)).all()
+    assert np.isnan(fp.scale(np.array([2.0, 2.0]))).all()
+    t = torch.arange(10, dtype=torch.float64, device='cuda')
+    out = fp.scale(t)
+    assert isinstance(out, torch.Tensor) and out.is_cuda
+    np.testing.assert_allclose(out.cpu().numpy(), np.arange(10) / 9.0, rtol=0, atol=0)
+    import json, os
+    with open(os.path.join(gu.GOLD, 'getdoms_golden.json')) as fh:
+        table = json.load(fh)
+    for row in table:
+        x = np.arange(row['L'] * 4, dtype=np.float32).reshape(row['L'], 4)
+        mat, key = fp.get_doms(x, row['dom'])
+        assert key == row['key'], row
+        assert mat.dtype == np.float64 and mat.shape[1] == 4
+        assert [int(v) for v in (mat[:, 0] / 4).astype(int)] == row['rows'], row
+
+
+def _oracle_rows(layers_per_seq, domains_per_seq, qdim):
+    rows, keys = [], []
+    for layers, doms in zip(layers_per_seq, domains_per_seq):
+        q = orc.quantize(layers, doms, qdim)
+        for k, v in q.items():
+            rows.append(v)
+            keys.append(k)
+    return keys, np.stack(rows).astype(np.int8)
+
+
+def test_ragged_batch_matches_oracle(dd):
+    """Many sequences of different lengths, multi-domain, both batch layouts."""
+    import torch
+    rng = np.random.default_rng(77)
+    D = 640
+    lens = [3, 17, 64, 158, 333, 500, 701, 1035, 40, 5]
+    layers_per_seq, doms_per_seq = [], []
+    for i, L in enumerate(lens):
+        layers_per_seq.append([make_input('esm', L, D, 9000 + 2 * i), make_input('esm', L, D, 9001 + 2 * i)])
+        doms = [f'1-{L}']
+        if L >= 40:
+            a = L // 3
+            doms = [f'1-{a}', f'{a + 1}-{L}', f'1-{a // 2},{a + 5}-{L - 3}', f'1-{L}']
+        doms_per_seq.append(doms)
+    keys, exp = _oracle_rows(layers_per_seq, doms_per_seq, [3, 80, 3, 80])
+    table = dd.PieceTable(lens, doms_per_seq)
+    assert table.keys == keys
+    # (a) list of per-sequence tensors
+    lt = [[torch.from_numpy(ls[k]).cuda() for ls in layers_per_seq] for k in range(2)]
+    out = dd.quantize_batch([dd.LayerBatch(lt[0], 3, 80), dd.LayerBatch(lt[1], 3, 80)], table)
+    np.testing.assert_array_equal(out.cpu().numpy(), exp)
+    # (b) one concatenated tensor per layer + row offsets
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    cat = [torch.cat(lt[k], dim=0) for k in range(2)]
+    out2 = dd.quantize_batch([dd.LayerBatch(cat[0], 3, 80, row_offsets=offs),
+                              dd.LayerBatch(cat[1], 3, 80, row_offsets=offs)], table)
+    np.testing.assert_array_equal(out2.cpu().numpy(), exp)
+    # (c) padded leading dimension (ld > D) and float64 storage
+    pad = torch.zeros((cat[0].shape[0], D + 64), dtype=torch.float64, device='cuda')
+    pad[:, :D] = cat[0].double()
+    out3 = dd.quantize_batch([dd.LayerBatch(pad[:, :D], 3, 80, row_offsets=offs)], table)
+    np.testing.assert_array_equal(out3.cpu().numpy(), exp[:, :240])
+    # (d) unaligned views fall back to the scalar-load kernel and still agree
+    shifted = torch.zeros((cat[0].shape[0], D + 1), dtype=torch.float32, device='cuda')
+    shifted[:, 1:] = cat[0]
+    out4 = dd.quantize_batch([dd.LayerBatch(shifted[:, 1:], 3, 80, row_offsets=offs)], table)
+    np.testing.assert_array_equal(out4.cpu().numpy(), exp[:, :240])
+
+
+def test_headline_shape_sample_and_properties(dd):
+    """BASELINE config 2 shape (L=500, D=1280, 2 layers) on a 48-sequence batch:
+    oracle parity on a sample plus the size-independent properties."""
+    import torch
+    n_seq, L, D = 48, 500, 1280
+    g = torch.Generator(device='cuda')
+    g.manual_seed(4242)
+    layers = []
+    for _ in range(2):
+        x = torch.randn((n_seq * L, D), generator=g, device='cuda')
+        x = x * torch.exp(torch.randn((1, D), generator=g, device='cuda')) + 5 * torch.randn((1, D), generator=g, device='cuda')
+        x[:, ::97] += 200.0
+        layers.append(x)
+    offs = np.arange(n_seq) * L
+    table = dd.PieceTable.whole_sequences([L] * n_seq)
+    lbs = [dd.LayerBatch(x, 3, 80, row_offsets=offs) for x in layers]
+    out = dd.quantize_batch(lbs, table).cpu().numpy()
+    assert out.shape == (n_seq, 480) and out.dtype == np.int8
+    # structural invariants of every committed reference fingerprint
+    rows = out.reshape(n_seq, 6, 80)
+    assert out.min() >= 0
+    assert ((rows == 127).sum(axis=2) == 1).all()
+    assert ((rows == 0).sum(axis=2) >= 1).all()
+    # oracle on a sample of sequences
+    for s in (0, 7, 23, 47):
+        ls = [x[s * L:(s + 1) * L].cpu().numpy() for x in layers]
+        q = orc.quantize(ls, [f'1-{L}'], [3, 80, 3, 80])[f'1-{L}']
+        np.testing.assert_array_equal(out[s].astype(np.int64), q)
+    # exact invariances: power-of-two rescaling, batch order, chunked scratch
+    out_scaled = dd.quantize_batch([dd.LayerBatch(x * 4.0, 3, 80, row_offsets=offs) for x in layers], table).cpu().numpy()
+    np.testing.assert_array_equal(out_scaled, out)
+    perm = np.random.default_rng(1).permutation(n_seq)
+    out_perm = dd.quantize_batch([dd.LayerBatch(x, 3, 80, row_offsets=offs[perm]) for x in layers], table).cpu().numpy()
+    np.testing.assert_array_equal(out_perm, out[perm])
+    ctx = dd.get_context(torch.cuda.current_device())
+    old = ctx.get_option('workspace_mb')
+    try:
+        ctx.set_option('workspace_mb', 16)
+        out_chunked = dd.quantize_batch(lbs, table).cpu().numpy()
+    finally:
+        ctx.set_option('workspace_mb', old)
+    np.testing.assert_array_equal(out_chunked, out)
+    # a domain given as a piece equals the same rows passed as their own sequence
+    table_sub = dd.PieceTable([L] * n_seq, [['101-400']] * n_seq)
+    out_sub = dd.quantize_batch(lbs, table_sub).cpu().numpy()
+    offs_sub = offs + 100
+    table_own = dd.PieceTable.whole_sequences([300] * n_seq)
+    out_own = dd.quantize_batch([dd.LayerBatch(x, 3, 80, row_offsets=offs_sub) for x in layers], table_own).cpu().numpy()
+    np.testing.assert_array_equal(out_sub, out_own)
+
+
+def test_large_ragged_lengths(dd):
+    """BASELINE config 3 flavour: L in [50, 2000], D = 1280, one layer, against the oracle."""
+    import torch
+    rng = np.random.default_rng(2024)
+    lens = [int(v) for v in rng.integers(50, 2001, size=12)] + [2000, 50]
+    xs = [make_input('esm', L, 1280, 5000 + i) for i, L in enumerate(lens)]
+    table = dd.PieceTable.whole_sequences(lens)
+    out = dd.quantize_batch([dd.LayerBatch([torch.from_numpy(x).cuda() for x in xs], 3, 80)], table).cpu().numpy()
+    for i, x in enumerate(xs):
+        q = orc.quantize([x], [f'1-{lens[i]}'], [3, 80])[f'1-{lens[i]}']
+        np.testing.assert_array_equal(out[i].astype(np.int64), q, err_msg=f'L={lens[i]}')
+
+
+def test_api_errors(dd):
+    import torch
+    x = torch.zeros((10, 128), device='cuda')
+    table = dd.PieceTable([10], [['1-10']])
+    with pytest.raises(dd.DctfpError):
+        dd.quantize_batch([dd.LayerBatch([x], 9, 80)], table)            # n above DCTFP_MAX_N
+    with pytest.raises(ValueError):
+        dd.quantize_batch([dd.LayerBatch([x], 3, 129)], table)           # m > D -> reshape error first
+    bad = dd.PieceTable([10], [['1-10']])
+    bad.pieces['n_rows'][0] = 11                                         # piece outside its sequence
+    with pytest.raises(dd.DctfpError):
+        dd.quantize_batch([dd.LayerBatch([x], 3, 80)], bad)
+    with pytest.raises(ValueError):
+        dd.LayerBatch([x.cpu()], 3, 80)                                  # host memory is refused
