@@ -34,6 +34,8 @@ def parse():
     ap.add_argument('--dim', type=int, default=1280)
     ap.add_argument('--layers', type=int, default=2)
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the CPU baseline leg')
+    ap.add_argument('--cpu-procs', type=int, default=0,
+                    help='CPU baseline worker processes (0 = usable cores, at most 16 = one GPU\'s CPU share on the pool)')
     ap.add_argument('--parity-sample', type=int, default=8)
     ap.add_argument('--opt', action='append', default=[], help='name=value passed to dctfp_set_option')
     return ap.parse_args()
@@ -72,7 +74,9 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import cpu_baseline as cb
-        cpu_baseline = cb.run(args.seq_len, args.dim, args.layers, tuple([3, 80] * args.layers), args.cpu_seconds)
+        procs = args.cpu_procs if args.cpu_procs > 0 else min(cb.usable_cores(), 16)
+        cpu_baseline = cb.run(args.seq_len, args.dim, args.layers, tuple([3, 80] * args.layers), args.cpu_seconds,
+                              procs=procs)
 
     import numpy as np
     import torch

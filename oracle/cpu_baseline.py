@@ -36,14 +36,34 @@ def _worker(args):
             return done, el
 
 
+def usable_cores(cap=64):
+    """Cores this process may really use: affinity mask, clipped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fh2:
+                        n = min(n, max(1, q // int(fh2.read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, cap))
+
+
 def run(n_rows=500, n_cols=1280, n_layers=2, qdim=(3, 80, 3, 80), seconds=12.0, procs=None):
     """Returns dict(value=fingerprints/s over all workers, cores=procs, sample=...)."""
     import multiprocessing as mp
     if procs is None:
-        try:
-            procs = len(os.sched_getaffinity(0))
-        except AttributeError:
-            procs = os.cpu_count() or 1
+        procs = usable_cores()
     ctx = mp.get_context('spawn')
     with ctx.Pool(procs) as pool:
         res = pool.map(_worker, [(100 + i, n_rows, n_cols, n_layers, list(qdim), seconds) for i in range(procs)])

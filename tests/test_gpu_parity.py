@@ -255,8 +255,10 @@ def test_api_errors(dd):
     table = dd.PieceTable([10], [['1-10']])
     with pytest.raises(dd.DctfpError):
         dd.quantize_batch([dd.LayerBatch([x], 9, 80)], table)            # n above DCTFP_MAX_N
-    with pytest.raises(ValueError):
-        dd.quantize_batch([dd.LayerBatch([x], 3, 129)], table)           # m > D -> reshape error first
+    with pytest.raises(dd.DctfpError):
+        dd.quantize_batch([dd.LayerBatch([x], 3, 129)], table)           # m above DCTFP_MAX_M
+    with pytest.raises(ValueError, match='cannot reshape array'):
+        dd.quantize_batch([dd.LayerBatch([x[:, :64]], 3, 80)], table)    # D < m: the reference's reshape error
     bad = dd.PieceTable([10], [['1-10']])
     bad.pieces['n_rows'][0] = 11                                         # piece outside its sequence
     with pytest.raises(dd.DctfpError):

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 CSV output of tools/profile_gpu.sh into a small markdown summary
+(per-kernel time stats, PMC counters per launch with the gfx950 FETCH_SIZE correction)."""
+
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(sub, pat):
+    return sorted(glob.glob(os.path.join(out, sub, '**', pat), recursive=True))
+
+
+def short(name):
+    name = name.split('(')[0]
+    for key in ('stage_a_kernel', 'stage_b_mfma_kernel', 'stage_b_valu_kernel', 'basis_kernel'):
+        if key in name:
+            return key
+    return name[-60:]
+
+
+print(f'# rocprofv3 summary ({os.path.basename(out)})\n')
+for f in find('trace', '*kernel_stats.csv'):
+    print('## kernel stats (rocprofv3 --kernel-trace --stats)\n')
+    print('| kernel | calls | total ms | avg us | min us | max us | % |')
+    print('|---|---|---|---|---|---|---|')
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | "
+                  f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | {float(r['MaxNs']) / 1e3:.1f} | {r['Percentage']} |")
+    print()
+
+counters = defaultdict(lambda: defaultdict(list))
+for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
+    for f in find(sub, '*counter_collection.csv'):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                counters[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+if counters:
+    print('## PMC counters (mean per launch; separate passes)\n')
+    print('| kernel | counter | launches | mean |')
+    print('|---|---|---|---|')
+    res = {}
+    for k, cs in sorted(counters.items()):
+        for c, vals in sorted(cs.items()):
+            m = sum(vals) / len(vals)
+            print(f'| {k} | {c} | {len(vals)} | {m:.6g} |')
+            res.setdefault(k, {})[c] = m
+    print()
+    if 'stage_a_kernel' in res and 'FETCH_SIZE' in res['stage_a_kernel']:
+        a = res['stage_a_kernel']
+        # MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+        # reads exactly 1/2 of a wide coalesced stream's bytes -> double it; WRITE_SIZE is exact.
+        fetch = 2.0 * a['FETCH_SIZE'] * 1024.0
+        write = a.get('WRITE_SIZE', 0.0) * 1024.0
+        print('## stage A HBM traffic per launch (gfx950 correction: 2 x FETCH_SIZE KiB + WRITE_SIZE KiB)\n')
+        print(f'- fetch {fetch / 1e9:.3f} GB, write {write / 1e9:.3f} GB, total {(fetch + write) / 1e9:.3f} GB')
+        with open(os.path.join(out, 'traffic.json'), 'w') as fh:
+            json.dump({'stage_a_hbm_bytes_per_launch': fetch + write, 'fetch_bytes': fetch, 'write_bytes': write,
+                       'raw': a}, fh, indent=1)
