@@ -85,10 +85,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X; the product path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=device)     # "nccl" is RCCL on ROCm; used for barrier + max only
-
     import dctdomain_amd as dd
+    from dctdomain_amd import dist as ddist
+    ddist.init('nccl', device)      # "nccl" is RCCL on ROCm; used for the barrier + max-over-ranks only
+
     ctx = dd.get_context(local_rank)
     for kv in args.opt:
         k, v = kv.split('=')
