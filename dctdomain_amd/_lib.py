@@ -10,6 +10,7 @@ import threading
 import numpy as np
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdctfp.so')
+RECCUT_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libreccut.so')
 
 DCTFP_OK = 0
 DCTFP_ERR_INVALID = -1
@@ -46,8 +47,8 @@ _lib = None
 _lib_lock = threading.Lock()
 
 EXPORTS = ('dctfp_version', 'dctfp_last_error', 'dctfp_create', 'dctfp_destroy', 'dctfp_quantize',
-           'dctfp_idct_quant', 'dctfp_scale', 'dctfp_gather_rows', 'dctfp_set_option',
-           'dctfp_get_option', 'dctfp_profile')
+           'dctfp_idct_quant', 'dctfp_scale', 'dctfp_gather_rows', 'dctfp_contact_topk',
+           'dctfp_contact_count', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile')
 
 
 def load():
@@ -73,12 +74,16 @@ def load():
         lib.dctfp_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         lib.dctfp_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        lib.dctfp_contact_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dctfp_contact_count.argtypes = [C.c_int32, C.c_double]
         lib.dctfp_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.dctfp_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
         lib.dctfp_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         for fn in EXPORTS:
-            if fn != 'dctfp_last_error':
+            if fn not in ('dctfp_last_error', 'dctfp_contact_count'):
                 getattr(lib, fn).restype = C.c_int
+        lib.dctfp_contact_count.restype = C.c_int64
         _lib = lib
         return lib
 
@@ -151,3 +156,26 @@ def get_context(device: int) -> Context:
             ctx = Context(device)
             _contexts[key] = ctx
         return ctx
+
+
+_reccut = None
+
+
+def load_reccut():
+    """Loads libreccut.so (include/reccut.h): the in-process domain cutter."""
+    global _reccut
+    with _lib_lock:
+        if _reccut is not None:
+            return _reccut
+        if not os.path.exists(RECCUT_LIB_PATH):
+            raise ImportError(f'{RECCUT_LIB_PATH} is missing: run python build_ext.py')
+        lib = C.CDLL(RECCUT_LIB_PATH)
+        lib.reccut_predict.restype = C.c_int
+        lib.reccut_predict.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
+                                       C.c_double, C.c_char_p, C.c_int64, C.POINTER(C.c_int32)]
+        lib.reccut_predict_batch.restype = C.c_int
+        lib.reccut_predict_batch.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                             C.c_int32]
+        _reccut = lib
+        return lib

@@ -738,4 +738,52 @@ int dctfp_gather_rows(dctfp_ctx* ctx, const void* embed, int32_t dtype, int64_t 
     return DCTFP_OK;
 }
 
+
+int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* ld, const int32_t* n_res,
+                       int32_t n_prot, double t, int32_t* out_i, int32_t* out_j, float* out_v,
+                       const int64_t* out_offs, int32_t* out_n, void* stream_v) {
+    if (!ctx || !maps || !ld || !n_res || !out_i || !out_j || !out_v || !out_offs || !out_n)
+        return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: NULL argument");
+    if (n_prot < 0) return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: negative count");
+    if (n_prot == 0) return DCTFP_OK;
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(ctx->device));
+    Staging& stg = ctx->staging[ctx->flip];
+    DevBuf& tab = ctx->tables[ctx->flip];
+    ctx->flip ^= 1;
+    int rc = stg.ensure((size_t)n_prot * sizeof(TopkJob));
+    if (rc) return rc;
+    TopkJob* h = (TopkJob*)stg.p;
+    for (int32_t p = 0; p < n_prot; ++p) {
+        const int64_t L = n_res[p];
+        if (L < 0 || (L > 0 && (!maps[p] || ld[p] < L)))
+            return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: protein %d: bad map", p);
+        h[p].map = (const float*)maps[p];
+        h[p].ld = ld[p];
+        h[p].n_res = (int32_t)L;
+        h[p].k = (int32_t)dctfp_contact_count((int32_t)L, t);
+        h[p].out_off = out_offs[p];
+        if (out_offs[p + 1] - out_offs[p] < h[p].k)
+            return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: protein %d: output room %lld < %d", p,
+                        (long long)(out_offs[p + 1] - out_offs[p]), h[p].k);
+    }
+    rc = tab.ensure((size_t)n_prot * sizeof(TopkJob));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(tab.p, stg.p, (size_t)n_prot * sizeof(TopkJob), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(stg.ev, stream));
+    stg.pending = true;
+    hipLaunchKernelGGL(contact_topk_kernel, dim3((unsigned)n_prot), dim3(1024), 0, stream, (const TopkJob*)tab.p, out_i,
+                       out_j, out_v, out_n);
+    HIP_TRY(hipGetLastError());
+    return DCTFP_OK;
+}
+
+int64_t dctfp_contact_count(int32_t n_res, double t) {
+    if (n_res < 6) return 0;
+    const int64_t cand = (int64_t)(n_res - 5) * (n_res - 4) / 2;  // pairs with j >= i + 5
+    int64_t tot = (int64_t)(t * (double)n_res);                   // int(t * slen), src/fingerprint.py:65
+    if (tot < 0) tot = 0;
+    return tot > cand ? cand : tot;
+}
+
 }  // extern "C"

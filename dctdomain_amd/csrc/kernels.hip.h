@@ -477,4 +477,115 @@ __global__ void gather_rows_kernel(const PieceA* __restrict__ pieces, int n_piec
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Contact top-k (Fingerprint.writece's selection, src/fingerprint.py:54-67): among the pairs
+// (i, j), j >= i + 5, of an L x L float32 contact map keep the k largest values; ties are
+// broken by (i, j) ascending (Python's stable sort with reverse=True).  One workgroup per
+// protein: 4-pass radix select on an order-preserving key, then a collection pass; only
+// when more elements tie at the threshold than are needed, wave 0 walks the candidates in
+// (i, j) order to take the first ones.  Output order is unspecified (the host sorts).
+// ---------------------------------------------------------------------------
+struct TopkJob {
+    const float* map;
+    int64_t ld;
+    int32_t n_res;
+    int32_t k;
+    int64_t out_off;
+};
+
+__device__ inline uint32_t topk_key(float v) {
+    if (v == 0.0f) v = 0.0f;  // -0.0 and +0.0 compare equal in the reference's sort
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void contact_topk_kernel(const TopkJob* __restrict__ jobs,
+                                                             int32_t* __restrict__ out_i, int32_t* __restrict__ out_j,
+                                                             float* __restrict__ out_v, int32_t* __restrict__ out_n) {
+    __shared__ int hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_need, s_eq, s_cnt;
+    const TopkJob job = jobs[blockIdx.x];
+    const int L = job.n_res;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int last_row = L - 6;  // rows 0 .. L-6 have at least one j >= i + 5
+    if (threadIdx.x == 0) {
+        s_prefix = 0;
+        s_need = job.k;
+        s_cnt = 0;
+        s_eq = 0;
+    }
+    __syncthreads();
+    if (job.k <= 0 || last_row < 0) {
+        if (threadIdx.x == 0) out_n[blockIdx.x] = 0;
+        return;
+    }
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        for (int i = wave; i <= last_row; i += nwaves) {
+            const float* __restrict__ row = job.map + (size_t)i * job.ld;
+            for (int j = i + 5 + lane; j < L; j += 64) {
+                const uint32_t key = topk_key(row[j]);
+                if (shift == 24 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255u], 1);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int need = s_need, b = 255;
+            for (; b > 0; --b) {
+                if (hist[b] >= need) break;
+                need -= hist[b];
+            }
+            s_prefix = prefix | ((uint32_t)b << shift);
+            s_need = need;  // elements still to take from bin b
+            s_eq = hist[b];
+        }
+        __syncthreads();
+    }
+    const uint32_t thr = s_prefix;
+    const int need_eq = s_need;
+    const bool all_ties = (s_eq == need_eq);
+    int32_t* __restrict__ oi = out_i + job.out_off;
+    int32_t* __restrict__ oj = out_j + job.out_off;
+    float* __restrict__ ov = out_v + job.out_off;
+    for (int i = wave; i <= last_row; i += nwaves) {
+        const float* __restrict__ row = job.map + (size_t)i * job.ld;
+        for (int j = i + 5 + lane; j < L; j += 64) {
+            const float v = row[j];
+            const uint32_t key = topk_key(v);
+            if (key > thr || (all_ties && key == thr)) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                oi[pos] = i;
+                oj[pos] = j;
+                ov[pos] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (!all_ties && wave == 0) {  // ordered walk for the first need_eq ties
+        int base = s_cnt, taken = 0;
+        for (int i = 0; i <= last_row && taken < need_eq; ++i) {
+            const float* __restrict__ row = job.map + (size_t)i * job.ld;
+            for (int j0 = i + 5; j0 < L && taken < need_eq; j0 += 64) {
+                const int j = j0 + lane;
+                const float v = (j < L) ? row[j] : 0.0f;
+                const bool hit = (j < L) && topk_key(v) == thr;
+                const unsigned long long m = __ballot(hit);
+                const int before = __popcll(m & ((1ull << lane) - 1ull));
+                if (hit && taken + before < need_eq) {
+                    const int pos = base + taken + before;
+                    oi[pos] = i;
+                    oj[pos] = j;
+                    ov[pos] = v;
+                }
+                taken += __popcll(m);
+            }
+        }
+    }
+    if (threadIdx.x == 0) out_n[blockIdx.x] = job.k;
+}
+
 }  // namespace dctfp

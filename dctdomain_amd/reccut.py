@@ -1,0 +1,132 @@
+"""Domain prediction step of the reference's ``Fingerprint`` (mgtools/DCTdomain
+src/fingerprint.py:45-107) without the Python pair list, the .ce temp file and the RecCut
+subprocess:
+
+* the top ``int(t * L)`` contacts with ``j >= i + 5`` are selected on the GPU
+  (``dctfp_contact_topk``; the reference builds and sorts an O(L^2) Python list, :54-67);
+* the domain boundaries come from ``libreccut.so`` in-process (include/reccut.h; the
+  reference spawns ``src/RecCut`` on a text file, :92-100).
+
+``write_ce`` still writes the byte-identical .ce text for users of that file format."""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+CUT1_DEFAULT = 0.08      # src/RecCut.cpp:12
+CUT2_DEFAULT = 0.07      # src/RecCut.cpp:13
+
+
+def _contact_tensor(contacts, n_res: int, device=None) -> torch.Tensor:
+    if isinstance(contacts, torch.Tensor):
+        t = contacts
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(contacts, dtype=np.float32)))
+    t = t.reshape(n_res, n_res)                 # cta = self.contacts.reshape(slen, slen)
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    if t.device.type != 'cuda':
+        if not torch.cuda.is_available():
+            raise RuntimeError('dctdomain_amd needs an MI355X GPU; there is no CPU fallback')
+        t = t.to(device if device is not None else torch.device('cuda', torch.cuda.current_device()))
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    return t
+
+
+def top_contacts_batch(maps: Sequence[torch.Tensor], t: float):
+    """Top ``int(t*L)`` contacts of each map.  Returns (offs, i, j, v) as numpy arrays: protein
+    p's contacts are ``[offs[p], offs[p+1])``, sorted by (-v, i, j) -- the order of the
+    reference's CON line."""
+    n = len(maps)
+    if n == 0:
+        return np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
+    device = maps[0].device
+    lib = _lib.load()
+    n_res = np.array([m.shape[0] for m in maps], dtype=np.int32)
+    counts = np.array([lib.dctfp_contact_count(int(L), float(t)) for L in n_res], dtype=np.int64)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=offs[1:])
+    total = int(offs[-1])
+    oi = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+    oj = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+    ov = torch.empty(max(total, 1), dtype=torch.float32, device=device)
+    on = torch.zeros(n, dtype=torch.int32, device=device)
+    ptrs = np.array([m.data_ptr() for m in maps], dtype=np.uint64)
+    lds = np.array([m.stride(0) if m.shape[0] > 1 else max(1, m.shape[1]) for m in maps], dtype=np.int64)
+    ctx = _lib.get_context(device.index)
+    stream = torch.cuda.current_stream(device)
+    _lib.check(lib.dctfp_contact_topk(ctx.handle, ptrs.ctypes.data, lds.ctypes.data, n_res.ctypes.data, n, float(t),
+                                      oi.data_ptr(), oj.data_ptr(), ov.data_ptr(), offs.ctypes.data, on.data_ptr(),
+                                      C.c_void_p(stream.cuda_stream)))
+    hi, hj, hv = oi[:total].cpu().numpy(), oj[:total].cpu().numpy(), ov[:total].cpu().numpy()
+    assert (on.cpu().numpy() == counts).all()
+    for p in range(n):
+        a, b = offs[p], offs[p + 1]
+        order = np.lexsort((hj[a:b], hi[a:b], -hv[a:b].astype(np.float64)))
+        hi[a:b], hj[a:b], hv[a:b] = hi[a:b][order], hj[a:b][order], hv[a:b][order]
+    return offs, hi, hj, hv
+
+
+def ce_text(pid: str, seq: str, ci, cj, cv) -> str:
+    """The .ce file body of src/fingerprint.py:69-80."""
+    slen = len(seq)
+    sout = ''
+    if len(ci):
+        sout = 'CON   ' + ','.join(f'{int(i)} {int(j)} {float(v):.6f}' for i, j, v in zip(ci, cj, cv))
+    return f'INF   {pid} {slen}\nSEQ   {seq}\nSS    {"C" * slen}\n{sout}\n'
+
+
+def write_ce(fp, outfile: str, t: float):
+    """``Fingerprint.writece`` (src/fingerprint.py:45-80): same file, byte for byte."""
+    slen = len(fp.seq)
+    cmap = _contact_tensor(fp.contacts, slen)
+    offs, ci, cj, cv = top_contacts_batch([cmap], t)
+    with open(outfile, 'w', encoding='utf8') as out_f:
+        out_f.write(ce_text(fp.pid, fp.seq, ci, cj, cv))
+
+
+def domains_from_contacts(n_res: Sequence[int], offs, ci, cj, cv, cut1=CUT1_DEFAULT, cut2=CUT2_DEFAULT,
+                          threads: int = 1) -> List[List[str]]:
+    """libreccut on a batch: per protein the list the reference gets from
+    ``stdout.strip().split()[2].split(';')[:-1]`` (src/fingerprint.py:103)."""
+    lib = _lib.load_reccut()
+    n = len(n_res)
+    n_res = np.ascontiguousarray(n_res, dtype=np.int32)
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    ci = np.ascontiguousarray(ci, dtype=np.int32)
+    cj = np.ascontiguousarray(cj, dtype=np.int32)
+    cv = np.ascontiguousarray(cv, dtype=np.float32)
+    stride = int(max(64, 16 * int(n_res.max()) if n else 64))
+    buf = np.zeros((n, stride), dtype=np.uint8)
+    nd = np.zeros(n, dtype=np.int32)
+    rc = np.zeros(n, dtype=np.int32)
+    ret = lib.reccut_predict_batch(n, n_res.ctypes.data, offs.ctypes.data, ci.ctypes.data, cj.ctypes.data,
+                                   cv.ctypes.data, float(cut1), float(cut2), buf.ctypes.data, stride, nd.ctypes.data,
+                                   rc.ctypes.data, int(threads))
+    if ret != 0:
+        raise RuntimeError(f'reccut_predict_batch failed: {ret}')
+    out = []
+    for p in range(n):
+        if rc[p] != 0:
+            # the reference would raise CalledProcessError (RecCut exit != 0) or crash
+            raise RuntimeError(f'reccut: protein {p}: error {int(rc[p])} '
+                               f'({"undefined behaviour in the reference at this input" if rc[p] == -3 else "invalid input"})')
+        text = bytes(buf[p]).split(b'\0', 1)[0].decode()
+        out.append(text.split(';')[:-1])
+    return out
+
+
+def predict_domains(fp, threshold: float) -> List[str]:
+    """The domain list ``Fingerprint.reccut`` appends (src/fingerprint.py:83-104), without the
+    trailing whole-protein entry (the caller adds it when there are several domains)."""
+    slen = len(fp.seq)
+    cmap = _contact_tensor(fp.contacts, slen)
+    offs, ci, cj, cv = top_contacts_batch([cmap], threshold)
+    return domains_from_contacts([slen], offs, ci, cj, cv)[0]

@@ -117,6 +117,19 @@ int dctfp_scale(dctfp_ctx* ctx, const double* vec, int64_t n, double* out, void*
 int dctfp_gather_rows(dctfp_ctx* ctx, const void* embed, int32_t dtype, int64_t n_rows, int64_t n_cols,
                       int64_t ld, const dctfp_piece* pieces, int64_t n_pieces, double* out, void* stream);
 
+/* The contact selection of Fingerprint.writece (src/fingerprint.py:54-67) for a batch of
+ * proteins: among the pairs (i, j), j >= i + 5, of each L x L float32 contact map keep the
+ * dctfp_contact_count(L, t) = min(int(t * L), number of such pairs) largest values, ties
+ * broken by (i, j) ascending as Python's stable reverse sort does.
+ *   maps, ld, n_res, out_offs : host arrays (maps[p] = device pointer of protein p's map)
+ *   out_i, out_j, out_v       : device arrays; protein p's entries start at out_offs[p], in
+ *                               unspecified order (sort by (-v, i, j) for the .ce text)
+ *   out_n                     : device int32[n_prot], entries written per protein */
+int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* ld, const int32_t* n_res,
+                       int32_t n_prot, double t, int32_t* out_i, int32_t* out_j, float* out_v,
+                       const int64_t* out_offs, int32_t* out_n, void* stream);
+int64_t dctfp_contact_count(int32_t n_res, double t);
+
 /* Tuning / instrumentation knobs (no reference counterpart).
  *   "stage_b"      0 = plain VALU kernel, 1 = MFMA f64 kernel (default)
  *   "a_waves"      waves per workgroup of the stage-A kernel (4, 8 or 16)

@@ -1,0 +1,171 @@
+"""Domain-prediction step: contact top-k selection + in-process RecCut.
+CPU part: the oracle and libreccut.so against golden vectors made by the reference's writece and
+the reference's own RecCut.cpp; GPU part: the top-k kernel and the Fingerprint.reccut surface."""
+
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import contacts_oracle as co
+from recipes import make_input, sha256_of
+from recipes_contacts import make_contacts
+
+with open(os.path.join(gu.GOLD, 'reccut_golden.json')) as fh:
+    CASES = json.load(fh)['cases']
+ARR = np.load(os.path.join(gu.GOLD, 'reccut_golden.npz'))
+IDS = [c['id'] for c in CASES]
+
+
+def build_map(case):
+    kw = {k: v for k, v in case['kw'].items() if k != 'pipeline'}
+    cmap = make_contacts(case['recipe'], case['L'], case['seed'], **kw)
+    assert sha256_of(cmap) == case['map_sha256']
+    return cmap
+
+
+@pytest.mark.parametrize('case', CASES, ids=IDS)
+def test_oracle_selection_and_ce_text(case):
+    cmap = build_map(case)
+    ci, cj, cv = co.top_contacts(cmap, case['t'])
+    assert len(ci) == case['n_contacts']
+    np.testing.assert_array_equal(ci, ARR[f"{case['id']}/i"])
+    np.testing.assert_array_equal(cj, ARR[f"{case['id']}/j"])
+    assert [f'{v:.6f}' for v in cv] == list(ARR[f"{case['id']}/vtext"])
+    text = co.ce_text(case['id'], case['seq'], ci, cj, cv)
+    assert hashlib.sha256(text.encode()).hexdigest() == case['ce_sha256']
+    if 'ce_text' in case:
+        assert text == case['ce_text']
+
+
+@pytest.mark.parametrize('case', CASES, ids=IDS)
+def test_libreccut_matches_reference_binary_golden(case):
+    from dctdomain_amd import reccut
+    cmap = build_map(case)
+    ci, cj = ARR[f"{case['id']}/i"], ARR[f"{case['id']}/j"]
+    cv = cmap[ci, cj] if len(ci) else np.zeros(0, np.float32)
+    doms = reccut.domains_from_contacts([case['L']], [0, len(ci)], ci, cj, cv)[0]
+    if len(doms) > 1:
+        doms = doms + [f"1-{case['L']}"]
+    assert case['reccut_rc'] == 0
+    assert doms == case['domains']
+    assert co.parse_reccut(case['reccut_stdout'], case['L']) == case['domains']
+
+
+@pytest.mark.skipif(not os.path.exists(co.REF_BIN), reason='oracle/_ref/RecCut not built')
+def test_libreccut_fuzz_against_reference_binary():
+    """Random block / interleaved graphs straight into both implementations."""
+    from dctdomain_amd import reccut
+    rng = np.random.default_rng(20240)
+    n_multi = n_disc = 0
+    for _ in range(120):
+        L = int(rng.integers(22, 360))
+        nb = int(rng.integers(1, 8))
+        bounds = np.sort(rng.choice(np.arange(1, L), size=min(nb - 1, L - 1), replace=False)) if nb > 1 else []
+        lab = np.zeros(L, int)
+        for b in bounds:
+            lab[b:] += 1
+        for _m in range(int(rng.integers(0, 3))):
+            if nb >= 3:
+                a, b = sorted(rng.choice(nb, 2, replace=False))
+                lab[lab == b] = a
+        same = lab[:, None] == lab[None, :]
+        p = rng.random((L, L)) * (same * rng.uniform(0.5, 1.0) + (~same) * rng.uniform(0.0, 0.3))
+        mask = np.triu(rng.random((L, L)) < rng.uniform(0.02, 0.3), 5)
+        ii, jj = np.nonzero(mask)
+        t = int(2.6 * L)
+        if len(ii) > t:
+            order = np.argsort(-p[ii, jj], kind='stable')[:t]
+            ii, jj = ii[order], jj[order]
+        pv = p[ii, jj].astype(np.float32)
+        text = co.ce_text('x', 'A' * L, ii, jj, pv)
+        rc, out = co.run_ref_binary(text)
+        assert rc == 0
+        exp = out.strip().split()[2].split(';')[:-1]
+        got = reccut.domains_from_contacts([L], [0, len(ii)], ii, jj, pv)[0]
+        assert got == exp, (L, exp, got)
+        n_multi += len(exp) > 1
+        n_disc += any(',' in d for d in exp)
+    assert n_multi > 30 and n_disc > 3
+
+
+def test_libreccut_batch_threads():
+    from dctdomain_amd import reccut
+    sel = [c for c in CASES if c['L'] >= 100][:8]
+    n_res, offs, ci, cj, cv = [], [0], [], [], []
+    for c in sel:
+        cmap = build_map(c)
+        i, j = ARR[f"{c['id']}/i"], ARR[f"{c['id']}/j"]
+        n_res.append(c['L']); ci.append(i); cj.append(j); cv.append(cmap[i, j]); offs.append(offs[-1] + len(i))
+    args = (n_res, offs, np.concatenate(ci), np.concatenate(cj), np.concatenate(cv))
+    one = reccut.domains_from_contacts(*args, threads=1)
+    four = reccut.domains_from_contacts(*args, threads=4)
+    assert one == four
+    for c, d in zip(sel, one):
+        assert (d + [f"1-{c['L']}"] if len(d) > 1 else d) == c['domains']
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', CASES, ids=IDS)
+def test_gpu_topk_writece_reccut(case, tmp_path):
+    import dctdomain_amd as dd
+    from dctdomain_amd import reccut
+    cmap = build_map(case)
+    fp = dd.Fingerprint(pid=case['id'], seq=case['seq'], contacts=cmap)
+    fn = str(tmp_path / 'x.ce')
+    fp.writece(fn, case['t'])
+    text = open(fn).read()
+    assert hashlib.sha256(text.encode()).hexdigest() == case['ce_sha256']
+    if abs(case['t'] - 2.6) < 1e-12:
+        fp.reccut(case['t'])
+        assert fp.domains == case['domains']
+    # the selection itself, entry by entry
+    import torch
+    offs, ci, cj, cv = reccut.top_contacts_batch([torch.from_numpy(cmap).cuda()], case['t'])
+    oi, oj, ov = co.top_contacts(cmap, case['t'])
+    np.testing.assert_array_equal(ci, oi)
+    np.testing.assert_array_equal(cj, oj)
+    np.testing.assert_array_equal(cv, ov)
+
+
+@pytest.mark.gpu
+def test_gpu_queue_cpu_pipeline_matches_reference():
+    """make_db.queue_cpu (src/make_db.py:29-30): reccut(2.6) then quantize([3,80,3,80])."""
+    import dctdomain_amd as dd
+    n = 0
+    for case in CASES:
+        if 'pipeline' not in case:
+            continue
+        cmap = build_map(case)
+        pl = case['pipeline']
+        e1 = make_input('esm', case['L'], pl['D'], pl['seeds'][0])
+        e2 = make_input('esm', case['L'], pl['D'], pl['seeds'][1])
+        assert [sha256_of(e1), sha256_of(e2)] == pl['sha']
+        fp = dd.Fingerprint(pid=case['id'], seq=case['seq'], embed={15: e1, 21: e2}, contacts=cmap)
+        fp.reccut(2.6)
+        fp.quantize([3, 80, 3, 80])
+        assert fp.domains == pl['keys']
+        for k_i, key in enumerate(pl['keys']):
+            np.testing.assert_array_equal(fp.quants[key], ARR[f"{case['id']}/q/{k_i}"].astype(np.int64))
+        n += 1
+    assert n >= 6
+
+
+@pytest.mark.gpu
+def test_gpu_topk_batch_mixed_lengths():
+    import torch
+    from dctdomain_amd import reccut
+    maps = [make_contacts(r, L, 900 + i) for i, (r, L) in enumerate(
+        [('blocks', 3), ('ties', 77), ('sparse', 640), ('flat', 50), ('blocks', 1035), ('negzero', 64), ('blocks', 6)])]
+    offs, ci, cj, cv = reccut.top_contacts_batch([torch.from_numpy(m).cuda() for m in maps], 2.6)
+    for p, m in enumerate(maps):
+        oi, oj, ov = co.top_contacts(m, 2.6)
+        a, b = offs[p], offs[p + 1]
+        np.testing.assert_array_equal(ci[a:b], oi)
+        np.testing.assert_array_equal(cj[a:b], oj)
+        np.testing.assert_array_equal(cv[a:b], ov)
