@@ -778,6 +778,67 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
     return DCTFP_OK;
 }
 
+int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, int32_t n_cols, int32_t square,
+                 void* stream_v) {
+    if (!ctx || (!jobs && n_jobs > 0)) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: NULL argument");
+    if (n_jobs < 0 || (!square && n_cols < 1)) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: bad count");
+    if (n_jobs == 0) return DCTFP_OK;
+    if (n_jobs > 65535 * 64) return fail(DCTFP_ERR_LIMIT, "dctfp_stitch: too many windows in one call");
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int32_t max_level = 0;
+    for (int64_t i = 0; i < n_jobs; ++i) {
+        const dctfp_stitch_job& j = jobs[i];
+        if (!j.src || !j.dst || j.n_rows < 1 || j.n_avg < 0 || j.n_avg > j.n_rows || j.level < 0 ||
+            j.ld_src < (square ? j.n_rows : n_cols) || j.ld_dst < (square ? j.n_rows : n_cols))
+            return fail(DCTFP_ERR_INVALID, "dctfp_stitch: window %lld is malformed", (long long)i);
+        if (j.level == 0 && j.n_avg != 0) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: window %lld: level 0 cannot average", (long long)i);
+        max_level = std::max(max_level, j.level);
+    }
+    Staging& stg = ctx->staging[ctx->flip];
+    DevBuf& tab = ctx->tables[ctx->flip];
+    ctx->flip ^= 1;
+    int rc = stg.ensure((size_t)n_jobs * sizeof(StitchJob));
+    if (rc) return rc;
+    rc = tab.ensure((size_t)n_jobs * sizeof(StitchJob));
+    if (rc) return rc;
+    // bucket the windows by level (stable), one launch per level in ascending order
+    StitchJob* h = (StitchJob*)stg.p;
+    std::vector<int64_t> start((size_t)max_level + 2, 0);
+    for (int64_t i = 0; i < n_jobs; ++i) start[(size_t)jobs[i].level + 1] += 1;
+    for (int32_t l = 0; l <= max_level; ++l) start[(size_t)l + 1] += start[(size_t)l];
+    std::vector<int64_t> fill(start.begin(), start.end() - 1);
+    std::vector<int32_t> max_rows((size_t)max_level + 1, 0);
+    for (int64_t i = 0; i < n_jobs; ++i) {
+        const dctfp_stitch_job& j = jobs[i];
+        StitchJob& o = h[fill[(size_t)j.level]++];
+        o.src = (const float*)j.src;
+        o.dst = (float*)j.dst;
+        o.n_rows = j.n_rows;
+        o.n_avg = j.n_avg;
+        o.ld_src = j.ld_src;
+        o.ld_dst = j.ld_dst;
+        max_rows[(size_t)j.level] = std::max(max_rows[(size_t)j.level], j.n_rows);
+    }
+    HIP_TRY(hipMemcpyAsync(tab.p, stg.p, (size_t)n_jobs * sizeof(StitchJob), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(stg.ev, stream));
+    stg.pending = true;
+    const StitchJob* d = (const StitchJob*)tab.p;
+    for (int32_t l = 0; l <= max_level; ++l) {
+        int64_t cnt = start[(size_t)l + 1] - start[(size_t)l];
+        int64_t done = 0;
+        while (done < cnt) {  // grid.y is limited to 65535
+            const unsigned ny = (unsigned)std::min<int64_t>(cnt - done, 65535);
+            dim3 grid((unsigned)((max_rows[(size_t)l] + 15) / 16), ny);
+            if (square) hipLaunchKernelGGL(stitch_contacts_kernel, grid, dim3(256), 0, stream, d + start[(size_t)l] + done);
+            else hipLaunchKernelGGL(stitch_rows_kernel, grid, dim3(256), 0, stream, d + start[(size_t)l] + done, n_cols);
+            HIP_TRY(hipGetLastError());
+            done += ny;
+        }
+    }
+    return DCTFP_OK;
+}
+
 int64_t dctfp_contact_count(int32_t n_res, double t) {
     if (n_res < 6) return 0;
     const int64_t cand = (int64_t)(n_res - 5) * (n_res - 4) / 2;  // pairs with j >= i + 5

@@ -588,4 +588,56 @@ __global__ __launch_bounds__(1024) void contact_topk_kernel(const TopkJob* __res
     if (threadIdx.x == 0) out_n[blockIdx.x] = job.k;
 }
 
+
+// ---------------------------------------------------------------------------
+// Chunk stitcher (Embedding.embed_seq / combine_contacts, src/embedding.py:123-150, :185-188).
+// A long sequence is embedded in windows of maxlen residues starting every maxlen - 200;
+// window i's first 200 rows are averaged with the running matrix' last 200 rows, the rest is
+// appended.  One launch per window index ("level") over all sequences of a batch, so the
+// reference's sequential semantics hold for any maxlen.  float32, (a + b) / 2 as there.
+// ---------------------------------------------------------------------------
+struct StitchJob {
+    const float* src;  // window matrix
+    float* dst;        // where the window's first row / top-left corner lands in the output
+    int32_t n_rows;    // window rows (embedding) or side (contacts)
+    int32_t n_avg;     // leading rows (embedding) / leading square side (contacts) that are averaged
+    int64_t ld_src;
+    int64_t ld_dst;
+};
+
+// grid.x = row blocks of 16, grid.y = job;  block = 256 threads over the columns
+__global__ __launch_bounds__(256) void stitch_rows_kernel(const StitchJob* __restrict__ jobs, int n_cols) {
+    const StitchJob job = jobs[blockIdx.y];
+    const int r0 = blockIdx.x * 16;
+    if (r0 >= job.n_rows) return;
+    const int r1 = min(job.n_rows, r0 + 16);
+    for (int r = r0; r < r1; ++r) {
+        const float* __restrict__ s = job.src + (size_t)r * job.ld_src;
+        float* __restrict__ d = job.dst + (size_t)r * job.ld_dst;
+        if (r < job.n_avg) {
+            for (int c = threadIdx.x; c < n_cols; c += 256) d[c] = (d[c] + s[c]) / 2.0f;
+        } else {
+            for (int c = threadIdx.x; c < n_cols; c += 256) d[c] = s[c];
+        }
+    }
+}
+
+// contacts: window square n_rows x n_rows; the leading n_avg x n_avg corner overlaps the
+// running map and is averaged, everything else of the square is new (the running map is 0
+// there: new_mat = zeros, src/embedding.py:143).
+__global__ __launch_bounds__(256) void stitch_contacts_kernel(const StitchJob* __restrict__ jobs) {
+    const StitchJob job = jobs[blockIdx.y];
+    const int r0 = blockIdx.x * 16;
+    if (r0 >= job.n_rows) return;
+    const int r1 = min(job.n_rows, r0 + 16);
+    for (int r = r0; r < r1; ++r) {
+        const float* __restrict__ s = job.src + (size_t)r * job.ld_src;
+        float* __restrict__ d = job.dst + (size_t)r * job.ld_dst;
+        for (int c = threadIdx.x; c < job.n_rows; c += 256) {
+            if (r < job.n_avg && c < job.n_avg) d[c] = (d[c] + s[c]) / 2.0f;
+            else d[c] = d[c] + s[c];
+        }
+    }
+}
+
 }  // namespace dctfp

@@ -1,0 +1,279 @@
+"""``Embedding`` / ``Batch`` / ``Model`` -- the producer side of the fingerprint path, mirroring
+mgtools/DCTdomain ``src/embedding.py`` (:17-278) with the chunk + overlap-average stitching on
+the GPU (``dctfp_stitch``) and the results left on the device for ``Fingerprint``.
+
+The language model is NOT part of this build (fair-esm is third-party and not
+installed, no weights).  ``Model`` loads the real ESM-2 when ``esm`` is importable; any object
+with the same two callables works (``SyntheticModel`` for tests and benchmarks):
+
+    model.esm_tokenizer([(pid, seq), ...]) -> (_, _, tokens[B, T+2])
+    model.esm_encoder(tokens, repr_layers=[15, 21], return_contacts=True)
+        -> {'representations': {layer: [B, T+2, D]}, 'contacts': [B, T, T]}
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+import torch
+
+from . import _lib
+
+OVERLAP = 200     # hard-coded in the reference, src/embedding.py:163
+
+
+class StitchJob(C.Structure):
+    """``dctfp_stitch_job`` (include/dctfp.h)."""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('ld_src', C.c_int64), ('ld_dst', C.c_int64),
+                ('n_rows', C.c_int32), ('n_avg', C.c_int32), ('level', C.c_int32), ('reserved', C.c_int32)]
+
+
+class Model:
+    """ESM-2 loader of the reference (src/embedding.py:17-56): esm2_t30_150M_UR50D, layers 15/21.
+    Needs the third-party ``esm`` package and its weights."""
+
+    def __init__(self, name: str = 'esm2_t30_150M_UR50D'):
+        try:
+            import esm  # noqa: F401
+        except ImportError as exc:
+            raise ImportError('fair-esm is not installed: pass a model object with esm_tokenizer / esm_encoder '
+                              '(e.g. dctdomain_amd.embedding.SyntheticModel) instead') from exc
+        import esm
+        self.esm_encoder, self.alphabet = getattr(esm.pretrained, name)()
+        self.esm_tokenizer = self.alphabet.get_batch_converter()
+        self.esm_encoder.eval()
+
+    def to_device(self, device):
+        self.esm_encoder.to(device)
+
+
+class SyntheticModel:
+    """Deterministic stand-in for the language model (tests, benchmarks, dry runs): embeddings and
+    contact maps are cheap functions of the tokens AND of the position inside the window, so that
+    overlapping windows disagree on shared residues the way a real model does."""
+
+    AA = 'ACDEFGHIKLMNPQRSTVWYXBZUO'
+
+    def __init__(self, dim: int = 640, layers=(15, 21), seed: int = 0, device=None):
+        self.dim = dim
+        self.layers = tuple(layers)
+        self.device = torch.device(device) if device is not None else torch.device('cpu')
+        g = torch.Generator().manual_seed(seed)
+        self.table = {l: torch.randn((len(self.AA) + 2, dim), generator=g) * (0.5 + 0.1 * k) for k, l in enumerate(self.layers)}
+        self.pos = torch.randn((4096, dim), generator=g) * 0.3
+        self.chan = 5.0 * torch.randn((1, dim), generator=g)
+        self.padding_idx = len(self.AA) + 1
+
+    def to_device(self, device):
+        self.device = torch.device(device)
+        self.table = {l: t.to(self.device) for l, t in self.table.items()}
+        self.pos = self.pos.to(self.device)
+        self.chan = self.chan.to(self.device)
+
+    def esm_tokenizer(self, pairs):
+        width = max(len(s) for _, s in pairs) + 2
+        tok = torch.full((len(pairs), width), self.padding_idx, dtype=torch.long)
+        for b, (_, s) in enumerate(pairs):
+            ids = [self.AA.find(ch) if ch in self.AA else 20 for ch in s]
+            tok[b, 0] = len(self.AA)
+            tok[b, 1:1 + len(s)] = torch.tensor(ids, dtype=torch.long)
+            tok[b, 1 + len(s)] = len(self.AA)
+        return None, None, tok
+
+    @torch.no_grad()
+    def esm_encoder(self, tokens, repr_layers=None, return_contacts=True):
+        tokens = tokens.to(self.device)
+        b, t = tokens.shape
+        reps = {}
+        for l in self.layers:
+            x = self.table[l][tokens] + self.pos[torch.arange(t, device=self.device) % self.pos.shape[0]][None]
+            x = x + 0.05 * x.mean(dim=1, keepdim=True) + self.chan
+            reps[l] = x.float()
+        n = t - 2
+        i = torch.arange(n, device=self.device)
+        near = 0.9 * torch.exp(-(i[:, None] - i[None, :]).abs().float() / 12.0)
+        h = (tokens[:, 1:-1, None] * 31 + tokens[:, None, 1:-1] * 17 + i[None, :, None] + i[None, None, :]) % 97
+        ct = near[None] + 0.25 * (h.float() / 97.0) * ((i[:, None] // 120) == (i[None, :] // 120))[None]
+        ct = 0.5 * (ct + ct.transpose(1, 2))
+        return {'representations': reps, 'contacts': ct.clamp(0, 1).float()}
+
+
+def _stitch(jobs: List[StitchJob], n_cols: int, square: bool, device):
+    arr = (StitchJob * len(jobs))(*jobs)
+    ctx = _lib.get_context(device.index)
+    stream = torch.cuda.current_stream(device)
+    _lib.check(ctx._lib.dctfp_stitch(ctx.handle, arr, len(jobs), int(n_cols), 1 if square else 0,
+                                     C.c_void_p(stream.cuda_stream)))
+
+
+def stitch_embeddings(windows: List[torch.Tensor], overlap: int = OVERLAP) -> torch.Tensor:
+    """``edata[lay][-olp:] = (edata[lay][-olp:] + emb[:olp]) / 2; cat(emb[olp:])`` over the windows
+    of one sequence and one layer (src/embedding.py:185-187), on the GPU."""
+    return stitch_embeddings_batch([windows], overlap)[0]
+
+
+def stitch_embeddings_batch(seq_windows: List[List[torch.Tensor]], overlap: int = OVERLAP) -> List[torch.Tensor]:
+    """Same for many sequences: one kernel launch per window index for the whole batch."""
+    outs, jobs, keep = [], [], []
+    device = None
+    n_cols = None
+    for windows in seq_windows:
+        ws = []
+        for w in windows:
+            if w.dtype != torch.float32:
+                w = w.float()
+            if w.stride(-1) != 1:
+                w = w.contiguous()
+            ws.append(w)
+        if device is None:
+            device, n_cols = ws[0].device, ws[0].shape[1]
+        if device.type != 'cuda':
+            raise ValueError('windows must be GPU tensors (no CPU fallback)')
+        total = ws[0].shape[0]
+        starts = [0]
+        for w in ws[1:]:
+            if w.shape[0] <= overlap or total < overlap:
+                raise ValueError('a window is not longer than the overlap')     # torch would fail to broadcast
+            starts.append(total - overlap)
+            total += w.shape[0] - overlap
+        out = torch.empty((total, n_cols), dtype=torch.float32, device=device)
+        for lvl, (w, st) in enumerate(zip(ws, starts)):
+            jobs.append(StitchJob(w.data_ptr(), out.data_ptr() + st * out.stride(0) * 4,
+                                  w.stride(0) if w.shape[0] > 1 else n_cols, out.stride(0), w.shape[0],
+                                  overlap if lvl else 0, lvl, 0))
+        keep.append(ws)
+        outs.append(out)
+    if jobs:
+        _stitch(jobs, n_cols, False, device)
+    return outs
+
+
+def stitch_contacts_batch(seq_windows: List[List[torch.Tensor]], inc: int) -> List[torch.Tensor]:
+    """``combine_contacts`` applied window after window (src/embedding.py:123-150, :188): window i's
+    map lands at offset ``inc * i``; the part overlapping the running map is averaged."""
+    outs, jobs, keep = [], [], []
+    device = None
+    for windows in seq_windows:
+        ws = [w.float().contiguous() if (w.dtype != torch.float32 or w.stride(-1) != 1) else w for w in windows]
+        if device is None:
+            device = ws[0].device
+        if device.type != 'cuda':
+            raise ValueError('windows must be GPU tensors (no CPU fallback)')
+        size = ws[0].shape[0]
+        geo = [(0, 0)]
+        for i, w in enumerate(ws[1:], start=1):
+            olp = inc * i
+            if olp > size:
+                raise ValueError('window offset beyond the running contact map')
+            geo.append((olp, size - olp))
+            size = olp + w.shape[0]
+        out = torch.zeros((size, size), dtype=torch.float32, device=device)
+        for lvl, (w, (off, navg)) in enumerate(zip(ws, geo)):
+            jobs.append(StitchJob(w.data_ptr(), out.data_ptr() + (off * out.stride(0) + off) * 4,
+                                  w.stride(0) if w.shape[0] > 1 else w.shape[1], out.stride(0), w.shape[0],
+                                  min(navg, w.shape[0]), lvl, 0))
+        keep.append(ws)
+        outs.append(out)
+    if jobs:
+        _stitch(jobs, 1, True, device)
+    return outs
+
+
+@dataclass
+class Embedding:
+    """One protein to embed (src/embedding.py:58-192).  ``embed`` / ``contacts`` end up as float32
+    torch tensors on the GPU (the reference copies them to numpy; ``Fingerprint`` takes either)."""
+    pid: str = field(default_factory=str)
+    seq: str = field(default_factory=str)
+    embed: dict = field(default_factory=dict)
+    contacts: object = field(default_factory=list)
+
+    def __post_init__(self):
+        self.contacts = np.array([])
+
+    def split_seq(self, maxlen: int, overlap: int) -> list:
+        """Windows of ``maxlen`` every ``maxlen - overlap`` residues; a window not longer than the
+        overlap is dropped (src/embedding.py:83-100)."""
+        subseqs = []
+        for i in range(0, len(self.seq), maxlen - overlap):
+            subseq = self.seq[i:i + maxlen]
+            if len(subseq) > overlap:
+                subseqs.append(subseq)
+        return subseqs
+
+    def extract_esm2(self, seq: str, model, device) -> dict:
+        """Model forward of one window (src/embedding.py:103-120)."""
+        _, _, batch_tokens = model.esm_tokenizer([(self.pid, seq)])
+        batch_tokens = batch_tokens.to(device)
+        with torch.no_grad():
+            return model.esm_encoder(batch_tokens, repr_layers=[15, 21], return_contacts=True)
+
+    def combine_contacts(self, mat1: torch.Tensor, mat2: torch.Tensor, inc: int, times: int) -> torch.Tensor:
+        """Running (n x n) map + window (m x m) map at offset ``inc * times`` (src/embedding.py:123-150)."""
+        olp = inc * times
+        mlen1, mlen2 = mat1.size(0), mat2.size(0)
+        out = torch.zeros((olp + mlen2, olp + mlen2), dtype=torch.float32, device=mat1.device)
+        jobs = [StitchJob(mat1.data_ptr(), out.data_ptr(), mat1.stride(0), out.stride(0), mlen1, 0, 0, 0),
+                StitchJob(mat2.data_ptr(), out.data_ptr() + (olp * out.stride(0) + olp) * 4, mat2.stride(0),
+                          out.stride(0), mlen2, min(max(mlen1 - olp, 0), mlen2), 1, 0)]
+        _stitch(jobs, 1, True, mat1.device)
+        return out
+
+    def embed_seq(self, model, device, layers: list, maxlen: int):
+        """Embeds the sequence window by window and stitches the windows (src/embedding.py:153-192)."""
+        olp = OVERLAP
+        subseqs = self.split_seq(maxlen, olp) if len(self.seq) > maxlen else [self.seq]
+        wins = {layer: [] for layer in layers}
+        cts = []
+        for seq in subseqs:
+            res = self.extract_esm2(seq, model, device)
+            for layer in layers:
+                wins[layer].append(res['representations'][layer][0][1:-1])
+            cts.append(res['contacts'][0])
+        if len(subseqs) == 1:
+            self.embed = {layer: wins[layer][0] for layer in layers}
+            self.contacts = cts[0]
+            return
+        stitched = stitch_embeddings_batch([wins[layer] for layer in layers], olp)
+        self.embed = {layer: stitched[k] for k, layer in enumerate(layers)}
+        self.contacts = stitch_contacts_batch([cts], maxlen - olp)[0]
+
+
+@dataclass
+class Batch:
+    """A batch of (pid, sequence) tuples to embed (src/embedding.py:195-278)."""
+    seqs: list = field(default_factory=list)
+    model: object = None
+    device: object = field(default_factory=str)
+    embeds: list = field(default_factory=list)
+
+    def embed_batch(self, layers: list, maxlen: int):
+        if len(self.seqs) == 1:
+            self.embed_single(layers, maxlen)
+        else:
+            self.embed_parallel(layers)
+
+    def embed_single(self, layers: list, maxlen: int):
+        for seq in self.seqs:
+            emb = Embedding(pid=seq[0], seq=seq[1])
+            emb.embed_seq(self.model, self.device, layers, maxlen)
+            self.embeds.append(emb)
+
+    def embed_parallel(self, layers: list):
+        """Several short sequences in one forward, no chunking (src/embedding.py:241-261)."""
+        _, _, batch_tokens = self.model.esm_tokenizer(self.seqs)
+        pad = getattr(getattr(self.model, 'alphabet', None), 'padding_idx', getattr(self.model, 'padding_idx', None))
+        batch_lens = (batch_tokens != pad).sum(1)
+        batch_tokens = batch_tokens.to(self.device)
+        with torch.no_grad():
+            res = self.model.esm_encoder(batch_tokens, repr_layers=[15, 21], return_contacts=True)
+        for i, seq in enumerate(self.seqs):
+            n = int(batch_lens[i])
+            emb = Embedding(pid=seq[0], seq=seq[1])
+            emb.contacts = res['contacts'][i][:n - 2, :n - 2]
+            for layer in layers:
+                emb.embed[layer] = res['representations'][layer][i][1:n - 1]
+            self.embeds.append(emb)

@@ -1,0 +1,233 @@
+"""Drop-in for mgtools/DCTdomain ``src/make_db.py``: FASTA -> SQLite ``.db`` (+ ``.index``,
+``-dct.npz``, ``.dom``) with the same command line (:167-177) and the same output layout, the
+fingerprinting running on MI355X.
+
+    python -m dctdomain_amd.make_db --fafile X.fasta --dbfile X [--maxlen 500] [--cpu N] [--gpu G]
+                                    [--noindex] [--nonpz] [--nodom] [--out LOG] [--model esm|synthetic]
+
+What changes underneath: the reference embeds on the GPU, copies every embedding to
+the host, pickles it into a ``multiprocessing.Pool`` and fingerprints one protein per worker call
+(:36-51).  Here the embeddings stay on the GPU; a flush of many proteins is fingerprinted by one
+batched contact top-k, one threaded in-process RecCut call and one ``dctfp_quantize`` launch
+(``fingerprint_batch``).  ``--cpu`` sizes the RecCut thread pool, ``--gpu G`` starts one process
+per GPU over disjoint, length-balanced shards; a single writer (the parent) fills the database in
+sequence order, so the files are identical for every G.
+"""
+
+from __future__ import annotations
+
+import argparse
+import datetime
+import logging
+import os
+from typing import List
+
+import numpy as np
+import torch
+
+from .database import Database
+from .fingerprint import Fingerprint
+
+LAYERS = [15, 21]                 # src/make_db.py:78, :138
+QDIM = [3, 80, 3, 80]             # src/make_db.py:30
+THRESHOLD = 2.6                   # src/make_db.py:29
+
+
+def queue_cpu(fp: Fingerprint) -> Fingerprint:
+    """One protein: predict domains, quantise (reference ``queue_cpu``, src/make_db.py:19-33)."""
+    fp.reccut(THRESHOLD)
+    fp.quantize(QDIM)
+    logging.info(f'{datetime.datetime.now()} Fingerprinted {fp.pid}')
+    return fp
+
+
+def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, threshold: float = THRESHOLD):
+    """``queue_cpu`` for many proteins at once: same ``domains`` / ``quants`` per object as calling
+    it one by one, with three batched steps instead of a process pool (src/make_db.py:36-51)."""
+    from . import reccut
+    from .batch import LayerBatch, PieceTable, quantize_batch
+    from .fingerprint import _to_device_matrix
+    if not fps:
+        return fps
+    lens = [len(fp.seq) for fp in fps]
+    maps = [reccut._contact_tensor(fp.contacts, n) for fp, n in zip(fps, lens)]
+    offs, ci, cj, cv = reccut.top_contacts_batch(maps, threshold)
+    doms = reccut.domains_from_contacts(lens, offs, ci, cj, cv, threads=max(1, threads))
+    for fp, d, n in zip(fps, doms, lens):
+        fp.domains.extend(d)
+        if len(d) > 1:
+            fp.domains.append(f'1-{n}')                        # src/fingerprint.py:106-107
+    keys0 = list(fps[0].embed.keys())
+    mats = [[_to_device_matrix(fp.embed[k]) for fp in fps] for k in keys0]
+    rows = [m.shape[0] for m in mats[0]]
+    table = PieceTable(rows, [fp.domains for fp in fps])
+    layers = [LayerBatch(mats[i], qdim[2 * i], qdim[2 * i + 1]) for i in range(len(keys0))]
+    out = quantize_batch(layers, table)
+    host = out.cpu().numpy().astype(np.int64) if table.n_domains else np.zeros((0, 0), np.int64)
+    blocks, off = [], 0
+    for i in range(len(keys0)):
+        nm = qdim[2 * i] * qdim[2 * i + 1]
+        blocks.append((off, nm))
+        off += nm
+    per_seq = [[] for _ in fps]
+    for row, s in enumerate(table.owner):
+        per_seq[s].append(row)
+    for fp, rws in zip(fps, per_seq):
+        for o, nm in blocks:                                   # layer-major, then domain order (:184-196)
+            for row in rws:
+                fp.quants.setdefault(table.keys[row], [])
+                if not isinstance(fp.quants[table.keys[row]], list):
+                    fp.quants[table.keys[row]] = list(fp.quants[table.keys[row]])
+                fp.quants[table.keys[row]].extend(host[row, o:o + nm].tolist())
+        for k, v in fp.quants.items():
+            fp.quants[k] = np.array(v)
+        fp.domains = list(fp.quants.keys())
+        logging.info(f'{datetime.datetime.now()} Fingerprinted {fp.pid}')
+    return fps
+
+
+def load_model(name: str, device):
+    from .embedding import Model, SyntheticModel
+    if name == 'synthetic':
+        model = SyntheticModel()
+    else:
+        model = Model()           # raises ImportError when fair-esm is not installed
+    model.to_device(device)
+    return model
+
+
+def _records(fps: List[Fingerprint]):
+    """Picklable (pid, domains, int8 matrix) triples for the writer."""
+    return [(fp.pid, list(fp.domains), np.array([fp.quants[d] for d in fp.domains], dtype=np.int8)) for fp in fps]
+
+
+class _Rec:
+    def __init__(self, pid, domains, mat):
+        self.pid, self.domains = pid, domains
+        self.quants = {d: mat[i] for i, d in enumerate(domains)}
+
+
+def process_sequences(seqs, model, device, maxlen: int, cpu: int, flush: int, sink):
+    """Embeds and fingerprints ``seqs`` [(pid, sequence)] on ``device``; ``sink(records)`` receives the
+    results of every flush."""
+    from .embedding import Batch
+    queue: List[Fingerprint] = []
+    batch, cur = [], 0
+
+    def run_batch(b):
+        bt = Batch(b, model, device)
+        bt.embed_batch(LAYERS, maxlen)
+        for emb in bt.embeds:
+            queue.append(Fingerprint(pid=emb.pid, seq=emb.seq, embed=emb.embed, contacts=emb.contacts))
+
+    for pid, seq in seqs:                          # same packing rule as Database.yield_seqs
+        if batch and (cur + len(seq) > maxlen or len(batch) > cpu):
+            run_batch(batch)
+            batch, cur = [], 0
+            if len(queue) >= flush:
+                sink(_records(fingerprint_batch(queue, threads=cpu)))
+                queue.clear()
+        batch.append((pid, seq))
+        cur += len(seq)
+    if batch:
+        run_batch(batch)
+    if queue:
+        sink(_records(fingerprint_batch(queue, threads=cpu)))
+
+
+def _gpu_worker(rank: int, n_gpu: int, shards, model_name: str, maxlen: int, cpu: int, flush: int, out_q):
+    n_dev = torch.cuda.device_count()
+    dev = torch.device('cuda', rank % max(1, n_dev))
+    torch.cuda.set_device(dev)
+    model = load_model(model_name, dev)
+    try:
+        process_sequences(shards[rank], model, dev, maxlen, cpu, flush, lambda recs: out_q.put(recs))
+    finally:
+        out_q.put(None)
+
+
+def run(args: argparse.Namespace) -> Database:
+    if args.out:
+        logging.basicConfig(level=logging.INFO, filename=args.out, filemode='w', format='%(message)s', force=True)
+    db = Database(args.dbfile, args.fafile)
+    print('Fingerprinting sequences...\n')
+    pending = db.pending()
+    order = {pid: i for i, (pid, _) in enumerate(pending)}
+    n_gpu = int(args.gpu) if args.gpu else 1
+    cpu = max(1, int(args.cpu))
+    results = {}
+
+    def sink(records):
+        for pid, domains, mat in records:
+            results[pid] = _Rec(pid, domains, mat)
+
+    if not torch.cuda.is_available():
+        raise RuntimeError('make_db needs an MI355X GPU: the fingerprint path has no CPU fallback')
+    if n_gpu <= 1:
+        dev = torch.device('cuda', torch.cuda.current_device())
+        model = load_model(args.model, dev)
+        process_sequences(pending, model, dev, args.maxlen, cpu, args.flush, sink)
+    else:
+        import torch.multiprocessing as mp
+        from .dist import balanced_shards
+        idx = balanced_shards([len(s) for _, s in pending], n_gpu)
+        shards = [[pending[i] for i in ix] for ix in idx]
+        ctx = mp.get_context('spawn')
+        out_q = ctx.Queue()
+        procs = [ctx.Process(target=_gpu_worker, args=(r, n_gpu, shards, args.model, args.maxlen, cpu, args.flush, out_q))
+                 for r in range(n_gpu)]
+        for p in procs:
+            p.start()
+        done = 0
+        while done < n_gpu:
+            item = out_q.get()
+            if item is None:
+                done += 1
+            else:
+                sink(item)
+        for p in procs:
+            p.join()
+            if p.exitcode != 0:
+                raise RuntimeError(f'GPU worker exited with code {p.exitcode}')
+    # single writer, table order = pending order (ascending length) whatever the number of GPUs
+    recs = sorted(results.values(), key=lambda r: order[r.pid])
+    db.add_fprints(recs)
+    db.rename_vid()
+    db.update_metadata()
+    if not args.noindex:
+        os.environ['OMP_NUM_THREADS'] = str(args.cpu)
+        print('Creating index...')
+        db.create_index()
+    if not args.nonpz:
+        db.save_fprints(f'{args.dbfile}-dct.npz')
+    if not args.nodom:
+        db.save_doms(f'{args.dbfile}.dom')
+    return db
+
+
+def build_parser() -> argparse.ArgumentParser:
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--fafile', type=str, required=False, help='fasta file to embed')
+    parser.add_argument('--dbfile', type=str, required=True, help='db file to write to')
+    parser.add_argument('--maxlen', type=int, default=500, help='max sequence length to embed')
+    parser.add_argument('--cpu', type=int, default=1, help='number of cpus to use')
+    parser.add_argument('--gpu', type=int, required=False, help='number of gpus to use')
+    parser.add_argument('--noindex', action='store_true', help='toggle for not creating index')
+    parser.add_argument('--nonpz', action='store_true', help='toggle for not saving fingerprints')
+    parser.add_argument('--nodom', action='store_true', help='toggle for not writing domains')
+    parser.add_argument('--out', type=str, default='', help='print progress to file')
+    # additions of this build
+    parser.add_argument('--model', choices=['esm', 'synthetic'], default='esm',
+                        help='language model: fair-esm ESM-2 (as the reference) or the synthetic stand-in')
+    parser.add_argument('--flush', type=int, default=256, help='proteins per batched fingerprint call')
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    db = run(args)
+    db.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -130,6 +130,30 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
                        const int64_t* out_offs, int32_t* out_n, void* stream);
 int64_t dctfp_contact_count(int32_t n_res, double t);
 
+/* The chunk stitcher of Embedding.embed_seq (src/embedding.py:153-192): a sequence longer than
+ * maxlen is embedded in windows; per layer `run[-200:] = (run[-200:] + new[:200]) / 2` then
+ * `cat(new[200:])` (:185-187), and for the contact maps combine_contacts (:123-150).  One job =
+ * one window of one sequence; `level` = the window's index in its sequence.  Windows are applied
+ * level by level (one launch per level for the whole batch), which keeps the reference's
+ * sequential semantics.  float32 in, float32 out, (a + b) / 2 as in the reference.
+ *   square = 0 : embeddings.  dst rows [0, n_avg) = (dst + src) / 2, rows [n_avg, n_rows) = src.
+ *   square = 1 : contact maps (n_cols ignored).  The n_rows x n_rows square at dst: its leading
+ *                n_avg x n_avg corner = (dst + src) / 2, the rest = dst + src; the caller zeroes
+ *                the output first (new_mat = torch.zeros, :143).
+ * jobs: host array; src/dst: device pointers. */
+typedef struct {
+    const void* src;
+    void* dst;
+    int64_t ld_src;
+    int64_t ld_dst;
+    int32_t n_rows;
+    int32_t n_avg;
+    int32_t level;
+    int32_t reserved;
+} dctfp_stitch_job;
+int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, int32_t n_cols, int32_t square,
+                 void* stream);
+
 /* Tuning / instrumentation knobs (no reference counterpart).
  *   "stage_b"      0 = plain VALU kernel, 1 = MFMA f64 kernel (default)
  *   "a_waves"      waves per workgroup of the stage-A kernel (4, 8 or 16)
