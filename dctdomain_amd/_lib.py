@@ -48,7 +48,7 @@ _lib_lock = threading.Lock()
 
 EXPORTS = ('dctfp_version', 'dctfp_last_error', 'dctfp_create', 'dctfp_destroy', 'dctfp_quantize',
            'dctfp_idct_quant', 'dctfp_scale', 'dctfp_gather_rows', 'dctfp_contact_topk',
-           'dctfp_contact_count', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile')
+           'dctfp_contact_count', 'dctfp_stitch', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile')
 
 
 def load():
@@ -62,6 +62,10 @@ def load():
                 f'{LIB_PATH} is missing: build the HIP extension first '
                 f'(python -c "import __graft_entry__ as g; g.build()" or python build_ext.py). '
                 f'dctdomain_amd has no CPU fallback.')
+        # torch first: its wheel bundles libamdhip64.so.7 / libhsa-runtime64 under the same SONAMEs as
+        # /opt/rocm.  Loading libdctfp.so before torch would pull the system copies in and leave the
+        # process with two HSA runtimes (the second one then sees "no ROCm-capable device").
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         lib.dctfp_version.restype = C.c_int
         lib.dctfp_last_error.restype = C.c_char_p
@@ -77,6 +81,7 @@ def load():
         lib.dctfp_contact_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.dctfp_contact_count.argtypes = [C.c_int32, C.c_double]
+        lib.dctfp_stitch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
         lib.dctfp_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.dctfp_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
         lib.dctfp_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]

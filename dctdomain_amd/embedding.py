@@ -88,9 +88,11 @@ class SyntheticModel:
         tokens = tokens.to(self.device)
         b, t = tokens.shape
         reps = {}
+        valid = (tokens != self.padding_idx).unsqueeze(-1).float()      # padding must not leak into a sequence
         for l in self.layers:
             x = self.table[l][tokens] + self.pos[torch.arange(t, device=self.device) % self.pos.shape[0]][None]
-            x = x + 0.05 * x.mean(dim=1, keepdim=True) + self.chan
+            mean = (x * valid).sum(dim=1, keepdim=True) / valid.sum(dim=1, keepdim=True)
+            x = x + 0.05 * mean + self.chan
             reps[l] = x.float()
         n = t - 2
         i = torch.arange(n, device=self.device)
