@@ -839,6 +839,35 @@ int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, i
     return DCTFP_OK;
 }
 
+int dctfp_l1_matrix(dctfp_ctx* ctx, const int8_t* a, int64_t na, int64_t lda, const int8_t* b, int64_t nb, int64_t ldb,
+                    int32_t d, int32_t* out, int64_t ldo, void* stream_v) {
+    if (!ctx || !a || !b || !out) return fail(DCTFP_ERR_INVALID, "dctfp_l1_matrix: NULL argument");
+    if (na < 0 || nb < 0 || d < 1 || lda < d || ldb < d || ldo < nb) return fail(DCTFP_ERR_INVALID, "dctfp_l1_matrix: bad shape");
+    if (na == 0 || nb == 0) return DCTFP_OK;
+    if ((na + 63) / 64 > 65535) return fail(DCTFP_ERR_LIMIT, "dctfp_l1_matrix: more than 4M rows per call");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    dim3 grid((unsigned)((nb + 63) / 64), (unsigned)((na + 63) / 64));
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | (uintptr_t)lda | (uintptr_t)ldb) & 3u) == 0;
+    if (aligned) hipLaunchKernelGGL((l1_matrix_kernel<true>), grid, dim3(256), 0, stream, a, na, lda, b, nb, ldb, d, out, ldo);
+    else hipLaunchKernelGGL((l1_matrix_kernel<false>), grid, dim3(256), 0, stream, a, na, lda, b, nb, ldb, d, out, ldo);
+    HIP_TRY(hipGetLastError());
+    return DCTFP_OK;
+}
+
+int dctfp_block_min(dctfp_ctx* ctx, const int32_t* dist, int64_t ldo, const int64_t* idx_a, int64_t npa,
+                    const int64_t* idx_b, int64_t npb, int32_t* out_min, int32_t* out_last, void* stream_v) {
+    if (!ctx || !dist || !idx_a || !idx_b || !out_min || !out_last) return fail(DCTFP_ERR_INVALID, "dctfp_block_min: NULL argument");
+    if (npa < 0 || npb < 0) return fail(DCTFP_ERR_INVALID, "dctfp_block_min: negative count");
+    if (npa == 0 || npb == 0) return DCTFP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t total = npa * npb;
+    hipLaunchKernelGGL(block_min_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_v, dist, ldo,
+                       idx_a, npa, idx_b, npb, out_min, out_last);
+    HIP_TRY(hipGetLastError());
+    return DCTFP_OK;
+}
+
 int64_t dctfp_contact_count(int32_t n_res, double t) {
     if (n_res < 6) return 0;
     const int64_t cand = (int64_t)(n_res - 5) * (n_res - 4) / 2;  // pairs with j >= i + 5

@@ -640,4 +640,93 @@ __global__ __launch_bounds__(256) void stitch_contacts_kernel(const StitchJob* _
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Fingerprint similarity (consumers: src/dct-sim.py:12-50, src/query_db.py:57,76).
+// L1 distance matrix between two sets of int8 fingerprints with v_sad_u8 (4 bytes per
+// instruction); 64 x 64 output tile per workgroup, both operand tiles staged in LDS in
+// chunks of 512 bytes (row stride 129 dwords: conflict-free column walks).
+// ---------------------------------------------------------------------------
+__device__ inline uint32_t load_bytes4(const int8_t* p, int n_valid) {  // n_valid in 1..4
+    uint32_t v = 0;
+    for (int i = 0; i < n_valid; ++i) v |= (uint32_t)(uint8_t)p[i] << (8 * i);
+    for (int i = n_valid; i < 4; ++i) v |= 0x80u << (8 * i);  // xor'ed back to 0 below
+    return v;
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void l1_matrix_kernel(const int8_t* __restrict__ a, int64_t na, int64_t lda,
+                                                         const int8_t* __restrict__ b, int64_t nb, int64_t ldb, int d,
+                                                         int32_t* __restrict__ out, int64_t ldo) {
+    constexpr int KC = 128;  // dwords per chunk
+    __shared__ uint32_t sa[64][KC + 1];
+    __shared__ uint32_t sb[64][KC + 1];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    uint32_t acc[4][4] = {};
+    const int nd = (d + 3) / 4;
+    for (int k0 = 0; k0 < nd; k0 += KC) {
+        const int kn = min(KC, nd - k0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * kn; i += 256) {
+            const int r = i / kn, k = i % kn;
+            const int byte0 = (k0 + k) * 4;
+            const int valid = min(4, d - byte0);
+            uint32_t va = 0x80808080u, vb = 0x80808080u;
+            if (r0 + r < na) {
+                const int8_t* p = a + (r0 + r) * lda + byte0;
+                va = (ALIGNED && valid == 4) ? *reinterpret_cast<const uint32_t*>(p) : load_bytes4(p, valid);
+            }
+            if (c0 + r < nb) {
+                const int8_t* p = b + (c0 + r) * ldb + byte0;
+                vb = (ALIGNED && valid == 4) ? *reinterpret_cast<const uint32_t*>(p) : load_bytes4(p, valid);
+            }
+            sa[r][k] = va ^ 0x80808080u;  // signed -> unsigned order, |x - y| unchanged
+            sb[r][k] = vb ^ 0x80808080u;
+        }
+        __syncthreads();
+        for (int k = 0; k < kn; ++k) {
+            uint32_t av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = sa[ty * 4 + i][k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = sb[tx + 16 * j][k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_sad_u8(av[i], bv[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t r = r0 + ty * 4 + i;
+        if (r >= na) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t c = c0 + tx + 16 * j;
+            if (c < nb) out[r * ldo + c] = (int32_t)acc[i][j];
+        }
+    }
+}
+
+// min over every (protein_a, protein_b) block of the distance matrix + the block's last entry
+// (domain_sim, src/dct-sim.py:28-50: the max similarity over domain pairs and the similarity
+// of the two last = whole-protein fingerprints).
+__global__ void block_min_kernel(const int32_t* __restrict__ dist, int64_t ldo, const int64_t* __restrict__ idx_a,
+                                 int64_t npa, const int64_t* __restrict__ idx_b, int64_t npb,
+                                 int32_t* __restrict__ out_min, int32_t* __restrict__ out_last) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npa * npb) return;
+    const int64_t pa = t / npb, pb = t % npb;
+    const int64_t a0 = idx_a[pa], a1 = idx_a[pa + 1], b0 = idx_b[pb], b1 = idx_b[pb + 1];
+    int32_t mn = 0x7fffffff, last = 0x7fffffff;
+    for (int64_t r = a0; r < a1; ++r)
+        for (int64_t c = b0; c < b1; ++c) {
+            last = dist[r * ldo + c];
+            mn = min(mn, last);
+        }
+    out_min[t] = mn;
+    out_last[t] = last;
+}
+
 }  // namespace dctfp

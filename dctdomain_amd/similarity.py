@@ -1,0 +1,61 @@
+"""GPU L1 distances between int8 fingerprints (``dctfp_l1_matrix`` / ``dctfp_block_min``): the
+arithmetic under the reference's two consumers, ``src/dct-sim.py`` and ``src/query_db.py``."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise RuntimeError('dctdomain_amd needs an MI355X GPU; there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def to_device_int8(fps) -> torch.Tensor:
+    t = fps if isinstance(fps, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(fps, dtype=np.int8)))
+    if t.dtype != torch.int8:
+        t = t.to(torch.int8)
+    if t.device.type != 'cuda':
+        t = t.to(_dev())
+    return t.contiguous()
+
+
+def l1_matrix(a, b) -> torch.Tensor:
+    """int32 (na, nb) matrix of L1 distances, on the GPU."""
+    ta, tb = to_device_int8(a), to_device_int8(b)
+    if ta.dim() != 2 or tb.dim() != 2 or ta.shape[1] != tb.shape[1]:
+        raise ValueError('fingerprint sets must be 2-D with equal width')
+    out = torch.empty((ta.shape[0], tb.shape[0]), dtype=torch.int32, device=ta.device)
+    if out.numel():
+        ctx = _lib.get_context(ta.device.index)
+        stream = torch.cuda.current_stream(ta.device)
+        lda = ta.stride(0) if ta.shape[0] > 1 else ta.shape[1]      # a size-1 axis may carry any stride
+        ldb = tb.stride(0) if tb.shape[0] > 1 else tb.shape[1]
+        ldo = out.stride(0) if out.shape[0] > 1 else out.shape[1]
+        _lib.check(ctx._lib.dctfp_l1_matrix(ctx.handle, ta.data_ptr(), ta.shape[0], lda, tb.data_ptr(),
+                                            tb.shape[0], ldb, ta.shape[1], out.data_ptr(), ldo,
+                                            C.c_void_p(stream.cuda_stream)))
+    return out
+
+
+def block_min(dist: torch.Tensor, idx_a, idx_b):
+    """(min, last) int32 arrays of shape (npa, npb) over the protein blocks of ``dist``."""
+    ia = torch.as_tensor(np.asarray(idx_a, dtype=np.int64), device=dist.device)
+    ib = torch.as_tensor(np.asarray(idx_b, dtype=np.int64), device=dist.device)
+    npa, npb = len(ia) - 1, len(ib) - 1
+    mn = torch.empty((npa, npb), dtype=torch.int32, device=dist.device)
+    last = torch.empty((npa, npb), dtype=torch.int32, device=dist.device)
+    if mn.numel():
+        ctx = _lib.get_context(dist.device.index)
+        stream = torch.cuda.current_stream(dist.device)
+        _lib.check(ctx._lib.dctfp_block_min(ctx.handle, dist.data_ptr(),
+                                            dist.stride(0) if dist.shape[0] > 1 else dist.shape[1], ia.data_ptr(), npa,
+                                            ib.data_ptr(), npb, mn.data_ptr(), last.data_ptr(),
+                                            C.c_void_p(stream.cuda_stream)))
+    return mn.cpu().numpy(), last.cpu().numpy()

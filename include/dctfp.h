@@ -154,6 +154,20 @@ typedef struct {
 int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, int32_t n_cols, int32_t square,
                  void* stream);
 
+/* L1 distance matrix between two sets of int8 fingerprints, the quantity under the
+ * reference's similarity scores 1 - min(L1 / 17000, 1) (src/dct-sim.py:12-26) and
+ * round(1 - L1 / 17000, 4) (src/query_db.py:57; FAISS METRIC_L1, :76):
+ *     out[i * ldo + j] = sum_k |a[i * lda + k] - b[j * ldb + k]|,  k < d.   All device pointers. */
+int dctfp_l1_matrix(dctfp_ctx* ctx, const int8_t* a, int64_t na, int64_t lda, const int8_t* b, int64_t nb, int64_t ldb,
+                    int32_t d, int32_t* out, int64_t ldo, void* stream);
+
+/* domain_sim (src/dct-sim.py:28-50) on a distance matrix: protein pa owns rows
+ * [idx_a[pa], idx_a[pa+1]), protein pb columns [idx_b[pb], idx_b[pb+1]) (device int64 prefix
+ * arrays, the npz "idx"); out_min[pa*npb+pb] = smallest distance of the block (-> DCTdomain),
+ * out_last = its last row / last column entry (-> DCTglobal). */
+int dctfp_block_min(dctfp_ctx* ctx, const int32_t* dist, int64_t ldo, const int64_t* idx_a, int64_t npa,
+                    const int64_t* idx_b, int64_t npb, int32_t* out_min, int32_t* out_last, void* stream);
+
 /* Tuning / instrumentation knobs (no reference counterpart).
  *   "stage_b"      0 = plain VALU kernel, 1 = MFMA f64 kernel (default)
  *   "a_waves"      waves per workgroup of the stage-A kernel (4, 8 or 16)

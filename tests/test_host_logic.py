@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     from dctdomain_amd import _lib
     with open(os.path.join(ROOT, 'include', 'dctfp.h')) as fh:
         header = fh.read()
-    declared = sorted(set(re.findall(r'\b(dctfp_[a-z_]+)\s*\(', header)))
+    declared = sorted(set(re.findall(r'\b(dctfp_[a-z0-9_]+)\s*\(', header)))
     assert len(declared) >= 11
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:

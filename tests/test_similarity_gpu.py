@@ -1,0 +1,73 @@
+"""Similarity consumers against the reference's committed outputs:
+bench/G6PD/G6PD-dctsim.txt (351 pairs from G6PD-dct.npz + G6PD.pair) and
+test/test/example-search.txt (400 lines of query_db output over example-dct.npz)."""
+
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+FIX = os.path.join(gu.GOLD, 'ref_fixtures')
+
+
+def test_l1_matrix_exact():
+    from dctdomain_amd.similarity import l1_matrix
+    rng = np.random.default_rng(0)
+    for na, nb, d in ((1, 1, 480), (43, 43, 480), (130, 77, 460), (5, 200, 255), (64, 65, 7), (3, 3, 1027)):
+        a = rng.integers(0, 128, size=(na, d)).astype(np.int8)
+        b = rng.integers(-128, 128, size=(nb, d)).astype(np.int8)
+        exp = np.abs(a.astype(np.int64)[:, None, :] - b.astype(np.int64)[None, :, :]).sum(-1)
+        got = l1_matrix(a, b).cpu().numpy()
+        np.testing.assert_array_equal(got, exp)
+
+
+def test_pair_sim_matches_G6PD_golden(tmp_path):
+    from dctdomain_amd import dct_sim
+    out = str(tmp_path / 'sim.txt')
+    dct_sim.main(['--dct', os.path.join(FIX, 'G6PD-dct.npz'), '--pair', os.path.join(FIX, 'G6PD.pair'), '--output', out])
+    got = open(out).read()
+    exp = open(os.path.join(FIX, 'G6PD-dctsim.txt')).read()
+    assert got == exp
+    assert got.count('\n') == 352
+
+
+def test_domain_sim_and_all_sim(tmp_path, capsys):
+    from dctdomain_amd import dct_sim
+    z = np.load(os.path.join(FIX, 'example-dct.npz'))
+    i0, i1, i2 = z['idx'][0], z['idx'][1], z['idx'][2]
+    a, b = z['dct'][i0:i1], z['dct'][i1:i2]
+    maxs, s = dct_sim.domain_sim(a, b)
+    ref = [1 - min(np.abs(x.astype(np.int64) - y.astype(np.int64)).sum() / 17000, 1) for x in a for y in b]
+    assert maxs == max(ref) and s == ref[-1]
+    assert dct_sim.prostSimilarity(a[0], a[0]) == 1
+    out = str(tmp_path / 'all.txt')
+    dct_sim.main(['--dct', os.path.join(FIX, 'example-dct.npz'), '--output', out])
+    lines = open(out).read().strip().split('\n')
+    assert len(lines) == 1 + 8 * 7 // 2
+    dbout = str(tmp_path / 'db.txt')
+    dct_sim.main(['--dct', os.path.join(FIX, 'example-dct.npz'), '--db', os.path.join(FIX, 'example-dct.npz'),
+                  '--output', dbout, '--top', '3'])
+    first = open(dbout).read().strip().split('\n')[1].split()
+    assert first[0] == first[1] and first[2] == '1.0'
+
+
+def test_query_search_matches_example_golden(tmp_path):
+    from dctdomain_amd import query_db
+    from dctdomain_amd.database import Database
+    z = np.load(os.path.join(FIX, 'example-dct.npz'))
+    db = Database(str(tmp_path / 'ex'), os.path.join(FIX, 'example.fasta'))
+    fps = []
+    for i, pid in enumerate(z['sid']):
+        s, e = z['idx'][i], z['idx'][i + 1]
+        doms = [str(d) for d in z['dom'][s:e]]
+        fps.append(SimpleNamespace(pid=str(pid), domains=doms, quants={d: z['dct'][s + k] for k, d in enumerate(doms)}))
+    db.add_fprints(fps)
+    db.rename_vid()
+    db.close()
+    out = str(tmp_path / 'search.txt')
+    query_db.main(['--query', str(tmp_path / 'ex.db'), '--db', str(tmp_path / 'ex.db'), '--out', out, '--khits', '50'])
+    assert open(out).read() == open(os.path.join(FIX, 'example-search.txt')).read()
