@@ -38,26 +38,51 @@ def parse():
                     help='CPU baseline worker processes (0 = usable cores, at most 16 = one GPU\'s CPU share on the pool)')
     ap.add_argument('--parity-sample', type=int, default=8)
     ap.add_argument('--opt', action='append', default=[], help='name=value passed to dctfp_set_option')
+    ap.add_argument('--workload', choices=['c2', 'c3', 'c4'], default='c2',
+                    help='c2 = headline (fixed L, whole-sequence domains); c3 = ragged L in [50,2000]; '
+                         'c4 = D=2560, L<=500, several domains per protein + whole protein')
     return ap.parse_args()
 
 
-def make_layer(torch, gen, n_seq, L, D, device):
+def make_layer(torch, gen, n_rows, D, device):
     """ESM-like synthetic embeddings, generated on the device in slabs:
     randn * exp(N(0,1) per channel) + N(0,5) per channel, 1 % channels offset by +-200."""
-    x = torch.empty((n_seq * L, D), dtype=torch.float32, device=device)
+    x = torch.empty((n_rows, D), dtype=torch.float32, device=device)
     ch_scale = torch.exp(torch.randn((1, D), generator=gen, device=device))
     ch_off = 5.0 * torch.randn((1, D), generator=gen, device=device)
     n_out = max(1, D // 100)
     idx = torch.randperm(D, generator=gen, device=device)[:n_out]
     sign = (torch.rand(n_out, generator=gen, device=device) < 0.5).float() * 2 - 1
     ch_off[0, idx] += 200.0 * sign
-    slab = max(1, (1 << 28) // (L * D))           # about 1 GiB of floats per slab
-    for s0 in range(0, n_seq, slab):
-        s1 = min(n_seq, s0 + slab)
-        v = x[s0 * L:s1 * L]
+    slab = max(1, (1 << 28) // D)                 # about 1 GiB of floats per slab
+    for r0 in range(0, n_rows, slab):
+        v = x[r0:min(n_rows, r0 + slab)]
         torch.randn(v.shape, generator=gen, device=device, out=v)
         v.mul_(ch_scale).add_(ch_off)
     return x
+
+
+def make_workload(args, rank, np):
+    """(lengths, domain strings per sequence or None for whole-sequence domains, D)."""
+    n_seq = args.n_seq
+    if args.workload == 'c2':
+        return np.full(n_seq, args.seq_len, dtype=np.int64), None, args.dim
+    rng = np.random.default_rng(2024 + rank)
+    if args.workload == 'c3':       # BASELINE config 3: ragged lengths, whole-sequence domains
+        return rng.integers(50, 2001, size=n_seq).astype(np.int64), None, args.dim
+    # BASELINE config 4 flavour: D = 2560, L <= 500, RecCut-like partitions (+ whole protein when > 1)
+    lengths = rng.integers(100, 501, size=n_seq).astype(np.int64)
+    doms = []
+    for L in lengths:
+        k = int(rng.integers(1, 7))
+        k = max(1, min(k, int(L) // 30))
+        if k == 1:
+            doms.append([f'1-{L}'])
+            continue
+        cuts = np.sort(rng.choice(np.arange(1, int(L) // 25), size=k - 1, replace=False)) * 25
+        edges = [0] + [int(c) for c in cuts] + [int(L)]
+        doms.append([f'{a + 1}-{b}' for a, b in zip(edges[:-1], edges[1:])] + [f'1-{L}'])
+    return lengths, doms, 2560
 
 
 def main():
@@ -94,14 +119,17 @@ def main():
         k, v = kv.split('=')
         ctx.set_option(k, int(v))
 
-    n_seq, L, D = args.n_seq, args.seq_len, args.dim
+    n_seq, L = args.n_seq, args.seq_len
+    lengths, doms, D = make_workload(args, rank, np)
+    total_rows = int(lengths.sum())
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
-    layers = [make_layer(torch, gen, n_seq, L, D, device) for _ in range(args.layers)]
-    offs = np.arange(n_seq, dtype=np.int64) * L
-    table = dd.PieceTable.whole_sequences([L] * n_seq)
+    layers = [make_layer(torch, gen, total_rows, D, device) for _ in range(args.layers)]
+    offs = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+    table = dd.PieceTable.whole_sequences(lengths) if doms is None else dd.PieceTable(lengths, doms)
     lbs = [dd.LayerBatch(x, 3, 80, row_offsets=offs) for x in layers]
-    out = torch.empty((n_seq, 240 * args.layers), dtype=torch.int8, device=device)
+    n_fp = table.n_domains
+    out = torch.empty((n_fp, 240 * args.layers), dtype=torch.int8, device=device)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -133,34 +161,50 @@ def main():
         from oracle import dct_oracle as orc
         host = out.cpu().numpy()
         pick = np.linspace(0, n_seq - 1, args.parity_sample).astype(int)
-        bad = 0
+        first_row = {}
+        for row, s in enumerate(table.owner):
+            first_row.setdefault(s, row)
+        bad = checked = 0
         for s in pick:
-            ls = [x[s * L:(s + 1) * L].cpu().numpy() for x in layers]
-            q = orc.quantize(ls, [f'1-{L}'], [3, 80] * args.layers)[f'1-{L}']
-            bad += int(np.any(host[s].astype(np.int64) != q))
-        parity = {'checked': int(len(pick)), 'mismatching_fingerprints': bad}
+            a, b = int(offs[s]), int(offs[s] + lengths[s])
+            ls = [x[a:b].cpu().numpy() for x in layers]
+            dl = [f'1-{int(lengths[s])}'] if doms is None else doms[s]
+            q = orc.quantize(ls, dl, [3, 80] * args.layers)
+            for k, key in enumerate(q):
+                bad += int(np.any(host[first_row[s] + k].astype(np.int64) != q[key]))
+                checked += 1
+        parity = {'checked': checked, 'mismatching_fingerprints': bad}
 
     if rank == 0:
-        total_fp = n_seq * world * args.steps
+        total_fp = n_fp * world * args.steps
         value = total_fp / elapsed
-        bytes_per_fp = args.layers * L * D * 4 + 240 * args.layers          # 5,120,480 B at C2
+        # algorithmic bytes: every embedding row read once per layer + the int8 output;
+        # 5,120,480 B per fingerprint at C2
+        batch_bytes = args.layers * total_rows * D * 4 + 240 * args.layers * n_fp
+        bytes_per_fp = batch_bytes / n_fp
         a_launch_ms = ms_k[0] / max(1, n_k[0])
-        a_bytes = bytes_per_fp * n_seq * (args.steps / max(1, n_k[0]))      # units one stage-A launch processes
+        a_bytes = batch_bytes * (args.steps / max(1, n_k[0]))               # units one stage-A launch processes
         achieved = a_bytes / (a_launch_ms * 1e-3) / 1e9 if a_launch_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tfile) and n_seq == 10000 and L == 500 and D == 1280:
+        if os.path.exists(tfile) and args.workload == 'c2' and n_seq == 10000 and L == 500 and D == 1280:
             with open(tfile) as fh:
                 traffic = json.load(fh).get('stage_a_hbm_bytes_per_launch')
         line = {
-            'metric': 'DCT fingerprints/sec on L=500 D=1280', 'value': value, 'unit': 'fingerprints/s',
+            'metric': 'DCT fingerprints/sec on L=500 D=1280' if args.workload == 'c2' else f'DCT fingerprints/sec ({args.workload})', 'value': value, 'unit': 'fingerprints/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'C2: {n_seq} sequences/GPU x {args.layers} layers of L={L} x D={D} float32 '
-                                   f'(ESM-like synthetic), one whole-sequence domain each, qdim [3,80]x{args.layers} '
-                                   f'-> {240 * args.layers} int8 per fingerprint',
-                       'sequences_per_gpu': n_seq, 'L': L, 'D': D, 'layers': args.layers, 'sharding': f'seq{world}'},
+            'config': {'workload': {
+                'c2': f'C2: {n_seq} sequences/GPU x {args.layers} layers of L={L} x D={D} float32 (ESM-like '
+                      f'synthetic), one whole-sequence domain each, qdim [3,80]x{args.layers} -> '
+                      f'{240 * args.layers} int8 per fingerprint',
+                'c3': f'C3: {n_seq} sequences/GPU, L ~ U[50,2000] ({total_rows} rows), D={D}, {args.layers} layers, '
+                      f'whole-sequence domains, ragged batch',
+                'c4': f'C4: {n_seq} sequences/GPU, L ~ U[100,500], D={D}, {args.layers} layers, 1-6 domains + whole '
+                      f'protein ({n_fp} fingerprints)'}[args.workload],
+                       'sequences_per_gpu': n_seq, 'fingerprints_per_gpu': n_fp, 'L': L if args.workload == 'c2' else None,
+                       'D': D, 'layers': args.layers, 'sharding': f'seq{world}'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': 'stage_a_kernel', 'avg_launch_ms': a_launch_ms,

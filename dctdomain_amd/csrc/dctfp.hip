@@ -140,13 +140,33 @@ struct EventPair {
 
 }  // namespace
 
+constexpr int kMaxSlots = 8;
+
 struct dctfp_ctx {
     int device = 0;
-    int64_t opt_stage_b = 1, opt_a_waves = 4, opt_a_unroll = 8, opt_profile = 0, opt_ws_mb = 4096;
+    int64_t opt_overlap = 4;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_a[kMaxSlots] = {}, ev_b[kMaxSlots] = {};
+    int ensure_side() {
+        if (side) return DCTFP_OK;
+        hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+        if (e != hipSuccess) { side = nullptr; g_err = std::string("hipStreamCreate: ") + hipGetErrorString(e); return DCTFP_ERR_HIP; }
+        for (int i = 0; i < kMaxSlots; ++i) {
+            if (hipEventCreateWithFlags(&ev_a[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_b[i], hipEventDisableTiming) != hipSuccess) {
+                g_err = "hipEventCreate failed";
+                return DCTFP_ERR_HIP;
+            }
+        }
+        return DCTFP_OK;
+    }
+    int64_t opt_stage_b = 1, opt_a_waves = 0, opt_a_unroll = 4, opt_profile = 0, opt_ws_mb = 4096, opt_a_stagger = 0;
     DevBuf tables[2];
     Staging staging[2];
     int flip = 0;
     DevBuf ws;       // yprime
+    DevBuf wpart;    // whole-protein partial slabs of fused groups
+    int64_t opt_fuse = 1;
     DevBuf scratch;  // generic idct_quant fs
     std::map<std::pair<int, int>, StEntry> st_cache;
     uint64_t tick = 0;
@@ -229,6 +249,9 @@ InvTab<N> make_inv() {
 
 struct AParams {
     const JobA* jobs;
+    const uint32_t* stream_jobs;
+    double* wpart;
+    bool fused;
     const PieceA* pieces;
     const double* basis;
     double* yprime;
@@ -236,6 +259,7 @@ struct AParams {
     int64_t ld;
     int ldy;
     int n_slabs;
+    int stagger;
     unsigned grid;
     hipStream_t stream;
 };
@@ -243,13 +267,42 @@ struct AParams {
 template <typename T, int N, int VEC, int WAVES, int UNROLL>
 void launch_a_impl(const AParams& p) {
     static const InvTab<N> inv = make_inv<N>();
-    hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream, p.jobs,
-                       p.pieces, p.basis, p.yprime, p.n_cols, p.ld, p.ldy, p.n_slabs, inv);
+    if (p.fused)
+        hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, true>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
+                           p.jobs, p.stream_jobs, p.pieces, p.basis, p.yprime, p.wpart, p.n_cols, p.ld, p.ldy, p.n_slabs,
+                           p.stagger, inv);
+    else
+        hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, false>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
+                           p.jobs, p.stream_jobs, p.pieces, p.basis, p.yprime, p.wpart, p.n_cols, p.ld, p.ldy, p.n_slabs,
+                           p.stagger, inv);
+}
+
+template <int N>
+void launch_combine_n(unsigned n_w, hipStream_t s, const WJob* wj, const double* wpart, double* yprime, int n_cols, int ldy) {
+    static const InvTab<N> inv = make_inv<N>();
+    hipLaunchKernelGGL((stage_a_combine_kernel<N>), dim3((unsigned)((ldy + 255) / 256), n_w), dim3(256), 0, s, wj, wpart,
+                       yprime, n_cols, ldy, inv);
+}
+
+void launch_combine(int n, unsigned n_w, hipStream_t s, const WJob* wj, const double* wpart, double* yprime, int n_cols,
+                    int ldy) {
+    switch (n) {
+        case 2: launch_combine_n<2>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
+        case 3: launch_combine_n<3>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
+        case 4: launch_combine_n<4>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
+        case 5: launch_combine_n<5>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
+        case 6: launch_combine_n<6>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
+        case 7: launch_combine_n<7>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
+        default: launch_combine_n<8>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
+    }
 }
 
 template <typename T, int N, int VEC>
 void launch_a_cfg(const AParams& p, int waves, int unroll) {
-    if (waves == 8) {
+    if (waves == 2) {
+        if (unroll == 4) launch_a_impl<T, N, VEC, 2, 4>(p);
+        else launch_a_impl<T, N, VEC, 2, 8>(p);
+    } else if (waves == 8) {
         if (unroll == 4) launch_a_impl<T, N, VEC, 8, 4>(p);
         else launch_a_impl<T, N, VEC, 8, 8>(p);
     } else if (waves == 16) {
@@ -365,11 +418,19 @@ int dctfp_destroy(dctfp_ctx* ctx) {
     for (auto& t : ctx->tables) t.release();
     for (auto& s : ctx->staging) s.release();
     ctx->ws.release();
+    ctx->wpart.release();
     ctx->scratch.release();
     for (auto& kv : ctx->st_cache) (void)hipFree(kv.second.dev);
     for (auto& e : ctx->events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
+    }
+    if (ctx->side) {
+        (void)hipStreamDestroy(ctx->side);
+        for (int i = 0; i < kMaxSlots; ++i) {
+            if (ctx->ev_a[i]) (void)hipEventDestroy(ctx->ev_a[i]);
+            if (ctx->ev_b[i]) (void)hipEventDestroy(ctx->ev_b[i]);
+        }
     }
     delete ctx;
     return DCTFP_OK;
@@ -382,11 +443,19 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "stage_b must be 0 or 1");
         ctx->opt_stage_b = value;
     } else if (n == "a_waves") {
-        if (value != 4 && value != 8 && value != 16) return fail(DCTFP_ERR_INVALID, "a_waves must be 4, 8 or 16");
+        if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16)
+            return fail(DCTFP_ERR_INVALID, "a_waves must be 0 (auto), 2, 4, 8 or 16");
         ctx->opt_a_waves = value;
     } else if (n == "a_unroll") {
         if (value != 4 && value != 8) return fail(DCTFP_ERR_INVALID, "a_unroll must be 4 or 8");
         ctx->opt_a_unroll = value;
+    } else if (n == "a_stagger") {
+        ctx->opt_a_stagger = value ? 1 : 0;
+    } else if (n == "fuse") {
+        ctx->opt_fuse = value ? 1 : 0;
+    } else if (n == "overlap") {
+        if (value < 1 || value > kMaxSlots) return fail(DCTFP_ERR_INVALID, "overlap must be 1..%d", kMaxSlots);
+        ctx->opt_overlap = value;
     } else if (n == "profile") {
         ctx->opt_profile = value ? 1 : 0;
     } else if (n == "workspace_mb") {
@@ -404,6 +473,9 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     if (n == "stage_b") *value = ctx->opt_stage_b;
     else if (n == "a_waves") *value = ctx->opt_a_waves;
     else if (n == "a_unroll") *value = ctx->opt_a_unroll;
+    else if (n == "a_stagger") *value = ctx->opt_a_stagger;
+    else if (n == "overlap") *value = ctx->opt_overlap;
+    else if (n == "fuse") *value = ctx->opt_fuse;
     else if (n == "profile") *value = ctx->opt_profile;
     else if (n == "workspace_mb") *value = ctx->opt_ws_mb;
     else return fail(DCTFP_ERR_INVALID, "unknown option '%s'", name);
@@ -494,6 +566,57 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                         ly.n_keep * ly.n_cols, ly.n_keep * ly.m_keep, l, ly.n_cols, ly.m_keep);
     }
 
+    // ---- fused groups: consecutive domains of one sequence whose last domain is the whole
+    // sequence and whose other domains tile it exactly (RecCut's output shape).  Their rows are
+    // streamed once: every part also accumulates the whole-protein coefficients.
+    std::vector<int32_t> grp_start((size_t)n_domains), part_ord((size_t)n_domains, -1);
+    std::vector<uint8_t> is_whole((size_t)n_domains, 0);
+    int64_t n_parts_total = 0, n_whole_total = 0;
+    for (int64_t d = 0; d < n_domains; ++d) grp_start[d] = (int32_t)d;
+    if (ctx->opt_fuse) {
+        std::vector<std::pair<int64_t, int64_t>> runs;  // scratch: (row_start, n_rows) of the parts
+        int64_t d = 0;
+        while (d < n_domains) {
+            const int32_t s0 = pieces[dom_first[d]].seq;
+            int64_t e = d;  // run [d, e] of domains of sequence s0
+            bool one_seq = true;
+            while (true) {
+                for (uint32_t k = 0; k < dom_np[e]; ++k)
+                    if (pieces[dom_first[e] + k].seq != s0) one_seq = false;
+                if (e + 1 < n_domains && pieces[dom_first[e + 1]].seq == s0) ++e;
+                else break;
+            }
+            bool ok = one_seq && e > d;
+            if (ok) {
+                const dctfp_piece& w = pieces[dom_first[e]];
+                ok = dom_np[e] == 1 && w.row_start == 0 && w.n_rows == seq_rows[s0];
+            }
+            if (ok) {
+                runs.clear();
+                for (int64_t q = d; q < e; ++q)
+                    for (uint32_t k = 0; k < dom_np[q]; ++k)
+                        runs.emplace_back(pieces[dom_first[q] + k].row_start, (int64_t)pieces[dom_first[q] + k].n_rows);
+                std::sort(runs.begin(), runs.end());
+                int64_t pos = 0;
+                for (auto& r : runs) {
+                    if (r.first != pos) { ok = false; break; }
+                    pos += r.second;
+                }
+                ok = ok && pos == seq_rows[s0];
+            }
+            if (ok) {
+                for (int64_t q = d; q < e; ++q) {
+                    part_ord[q] = (int32_t)n_parts_total++;
+                    grp_start[q] = (int32_t)d;
+                }
+                grp_start[e] = (int32_t)d;
+                is_whole[e] = 1;
+                ++n_whole_total;
+            }
+            d = e + 1;
+        }
+    }
+
     // ---- groups of consecutive layers with the same geometry ----------------------
     int32_t l0 = 0;
     while (l0 < n_layers) {
@@ -511,7 +634,9 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const size_t off_jobb = 0;
         const size_t off_joba = align_up(off_jobb + (size_t)n_jobs * sizeof(JobB), 16);
         const size_t off_piece = align_up(off_joba + (size_t)n_jobs * sizeof(JobA), 16);
-        const size_t off_lens = align_up(off_piece + (size_t)ng * n_pieces * sizeof(PieceA), 16);
+        const size_t off_stream = align_up(off_piece + (size_t)ng * n_pieces * sizeof(PieceA), 16);
+        const size_t off_wjob = align_up(off_stream + (size_t)n_jobs * sizeof(uint32_t), 16);
+        const size_t off_lens = align_up(off_wjob + (size_t)ng * n_whole_total * sizeof(WJob), 16);
         Staging& stg = ctx->staging[ctx->flip];
         DevBuf& tab = ctx->tables[ctx->flip];
         ctx->flip ^= 1;
@@ -523,6 +648,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         JobB* hjb = (JobB*)(h + off_jobb);
         JobA* hja = (JobA*)(h + off_joba);
         PieceA* hpc = (PieceA*)(h + off_piece);
+        uint32_t* hstream = (uint32_t*)(h + off_stream);
+        WJob* hwj = (WJob*)(h + off_wjob);
         uint32_t* hlens = (uint32_t*)(h + off_lens);
 
         const bool trivial = (n == 1 || m == 1);  // single resampled value -> 0/0 -> 0
@@ -547,6 +674,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             hlens[i] = ulen[i];
             hoffs[i] = uoff[i];
         }
+        const int ldy_pre = (int)align_up((size_t)g.n_cols, 32);
+        const size_t wpart_bytes = (size_t)ng * n_parts_total * nk * ldy_pre * sizeof(double);
+        const bool fuse = !trivial && n_parts_total > 0 && wpart_bytes <= ((size_t)ctx->opt_ws_mb << 20) &&
+                          (int64_t)ng * n_parts_total < 0x7fffffff;
         bool vec_ok = true;
         for (int li = 0; li < ng; ++li) {
             const dctfp_layer& ly = layers[l0 + li];
@@ -557,6 +688,16 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 hja[job].n_pieces = dom_np[d];
                 hja[job].n_rows = dom_len[d];
                 hja[job].basis_off = trivial ? 0u : len_off[dom_len[d]];
+                hja[job].w_slot = -1;
+                hja[job].w_basis_off = 0;
+                hja[job].w_ref = nullptr;
+                if (fuse && part_ord[d] >= 0) {
+                    int64_t w = d;
+                    while (!is_whole[w]) ++w;  // the whole-protein domain closes the group
+                    hja[job].w_slot = (int32_t)((int64_t)li * n_parts_total + part_ord[d]);
+                    hja[job].w_basis_off = len_off[dom_len[w]];
+                    hja[job].w_ref = ly.seq_data[pieces[dom_first[w]].seq];
+                }
             }
             uint32_t t0 = 0;
             int32_t prev_dom = -1;
@@ -568,6 +709,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 o.ptr = (const char*)ly.seq_data[pc.seq] + (size_t)pc.row_start * (size_t)ly.ld * esz;
                 o.n_rows = (uint32_t)pc.n_rows;
                 o.t0 = t0;
+                o.w0 = (uint32_t)pc.row_start;
+                o.reserved = 0;
                 t0 += (uint32_t)pc.n_rows;
             }
             for (int32_t s = 0; s < n_seq; ++s)
@@ -576,6 +719,62 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const int vec_want = g.dtype == DCTFP_F32 ? 4 : 2;
         if (((size_t)g.ld * esz) % 16 != 0 || g.n_cols % vec_want != 0) vec_ok = false;
         const int vec = vec_ok ? vec_want : 1;
+
+        // ---- chunk plan.  The float64 scratch is a ring of `slots` regions of `sub` jobs each;
+        // a chunk never splits a fused group (its whole-protein job needs every part's slab).
+        struct Chunk { int64_t j0, j1, s0, sn, w0, wn; };
+        int64_t avg_rows = 0;  // rows per streamed job (launch-shape heuristic)
+        {
+            int64_t rows = 0, cnt = 0;
+            for (int64_t d = 0; d < n_domains; ++d)
+                if (!(fuse && is_whole[d])) {
+                    rows += dom_len[d];
+                    ++cnt;
+                }
+            avg_rows = cnt ? rows / cnt : 0;
+        }
+        std::vector<Chunk> plan;
+        const size_t job_bytes = (size_t)n * ldy_pre * sizeof(double);
+        const int n_slabs = (ldy_pre + 64 * vec - 1) / (64 * vec);
+        int slots = 1;
+        int64_t sub = 1;
+        if (!trivial) {
+            int64_t cap_jobs = std::max<int64_t>(1, (int64_t)(((size_t)ctx->opt_ws_mb << 20) / job_bytes));
+            cap_jobs = std::min<int64_t>(cap_jobs, n_jobs);
+            if (ctx->opt_overlap > 1 && n_jobs >= 2048 && cap_jobs >= 2048) slots = (int)std::min<int64_t>(ctx->opt_overlap, kMaxSlots);
+            sub = (cap_jobs + slots - 1) / slots;
+            sub = std::min<int64_t>(sub, (int64_t)0x7fffffff / n_slabs);
+            sub = std::max<int64_t>(sub, 1);
+            int64_t max_group = 1;
+            if (fuse)
+                for (int64_t d = 0; d < n_domains; ++d) max_group = std::max<int64_t>(max_group, d - grp_start[d] + 1);
+            sub = std::max<int64_t>(sub, max_group);  // a group always fits one region
+            int64_t ns = 0, nw = 0;
+            for (int64_t j0 = 0; j0 < n_jobs;) {
+                int64_t j1 = std::min<int64_t>(j0 + sub, n_jobs);
+                if (fuse && j1 < n_jobs) {
+                    const int64_t d = j1 % n_domains;
+                    if (d != 0 && grp_start[d] < d) j1 -= d - grp_start[d];  // back to the group's first job
+                }
+                Chunk ck{j0, j1, ns, 0, nw, 0};
+                for (int64_t j = j0; j < j1; ++j) {
+                    const int64_t li = j / n_domains, d = j % n_domains;
+                    if (fuse && is_whole[d]) {
+                        WJob& wj = hwj[nw++];
+                        wj.job = (uint32_t)(j - j0);
+                        wj.slot_begin = (uint32_t)(li * n_parts_total + part_ord[grp_start[d]]);
+                        wj.n_parts = (uint32_t)(d - grp_start[d]);
+                        wj.reserved = 0;
+                        ++ck.wn;
+                    } else {
+                        hstream[ns++] = (uint32_t)(j - j0);
+                        ++ck.sn;
+                    }
+                }
+                plan.push_back(ck);
+                j0 = j1;
+            }
+        }
 
         const size_t tab_bytes = align_up(off_lens + 2 * nu * sizeof(uint32_t), 16);
         const size_t off_basis = align_up(tab_bytes, 256);
@@ -588,6 +787,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const JobB* djb = (const JobB*)(dt + off_jobb);
         const JobA* dja = (const JobA*)(dt + off_joba);
         const PieceA* dpc = (const PieceA*)(dt + off_piece);
+        const uint32_t* dstream = (const uint32_t*)(dt + off_stream);
+        const WJob* dwj = (const WJob*)(dt + off_wjob);
         const uint32_t* dlens = (const uint32_t*)(dt + off_lens);
         const uint32_t* doffs = dlens + nu;
         double* dbasis = (double*)(dt + off_basis);
@@ -614,49 +815,86 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             HIP_TRY(hipGetLastError());
         }
 
-        // jobs per chunk, bounded by the scratch cap and by the 2^31 grid limit
-        const size_t job_bytes = (size_t)n * ldy * sizeof(double);
-        const int n_slabs = (ldy + 64 * vec - 1) / (64 * vec);
-        int64_t chunk = std::max<int64_t>(1, (int64_t)(((size_t)ctx->opt_ws_mb << 20) / job_bytes));
-        chunk = std::min<int64_t>(chunk, (int64_t)0x7fffffff / n_slabs);
-        chunk = std::min<int64_t>(chunk, n_jobs);
-        rc = ctx->ws.ensure((size_t)chunk * job_bytes);
+        // Stage A of chunk c runs on the caller's stream, stage B of it on the context's side
+        // stream, so the MFMA-bound stage B of one chunk overlaps the HBM-bound stage A of the next.
+        if (ldy != ldy_pre) return fail(DCTFP_ERR_INVALID, "internal: basis width mismatch");
+        rc = ctx->ws.ensure((size_t)sub * slots * job_bytes);
         if (rc) return rc;
-        double* yprime = (double*)ctx->ws.p;
+        if (fuse) {
+            rc = ctx->wpart.ensure(wpart_bytes);
+            if (rc) return rc;
+        }
+        const bool side = slots > 1;
+        if (side) {
+            rc = ctx->ensure_side();
+            if (rc) return rc;
+        }
+        hipStream_t sb = side ? ctx->side : stream;
 
-        for (int64_t j0 = 0; j0 < n_jobs; j0 += chunk) {
-            const int64_t jn = std::min<int64_t>(chunk, n_jobs - j0);
-            AParams ap;
-            ap.jobs = dja + j0;
-            ap.pieces = dpc;
-            ap.basis = dbasis;
-            ap.yprime = yprime;
-            ap.n_cols = g.n_cols;
-            ap.ld = g.ld;
-            ap.ldy = ldy;
-            ap.n_slabs = n_slabs;
-            ap.grid = (unsigned)(jn * n_slabs);
-            ap.stream = stream;
+        int64_t c = 0;
+        for (const Chunk& ck : plan) {
+            const int64_t j0 = ck.j0, jn = ck.j1 - ck.j0;
+            const int slot = (int)(c % slots);
+            double* yprime = (double*)((char*)ctx->ws.p + (size_t)slot * sub * job_bytes);
+            if (side && c >= slots) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_b[slot], 0));  // slot free again?
             EventPair* ep = nullptr;
             rc = prof_begin(ctx, 0, stream, &ep);
             if (rc) return rc;
-            launch_a(ap, g.dtype, vec, n, (int)ctx->opt_a_waves, (int)ctx->opt_a_unroll);
-            HIP_TRY(hipGetLastError());
+            if (ck.sn > 0) {
+                AParams ap;
+                ap.jobs = dja + j0;
+                ap.stream_jobs = dstream + ck.s0;
+                ap.wpart = (double*)ctx->wpart.p;
+                ap.fused = fuse;
+                ap.pieces = dpc;
+                ap.basis = dbasis;
+                ap.yprime = yprime;
+                ap.n_cols = g.n_cols;
+                ap.ld = g.ld;
+                ap.ldy = ldy;
+                ap.n_slabs = n_slabs;
+                ap.stagger = (int)ctx->opt_a_stagger;
+                ap.grid = (unsigned)(ck.sn * n_slabs);
+                ap.stream = stream;
+                int waves = (int)ctx->opt_a_waves;
+                if (waves == 0) {  // auto: short jobs want more, smaller workgroups per CU
+                    waves = avg_rows >= 320 ? 8 : (avg_rows >= 48 ? 4 : 2);
+                }
+                launch_a(ap, g.dtype, vec, n, waves, (int)ctx->opt_a_unroll);
+                HIP_TRY(hipGetLastError());
+            }
+            if (ck.wn > 0) {
+                for (int64_t w = 0; w < ck.wn; w += 65535) {
+                    const unsigned nw = (unsigned)std::min<int64_t>(65535, ck.wn - w);
+                    launch_combine(n, nw, stream, dwj + ck.w0 + w, (const double*)ctx->wpart.p, yprime, g.n_cols, ldy);
+                    HIP_TRY(hipGetLastError());
+                }
+            }
             rc = prof_end(ep, stream);
             if (rc) return rc;
+            if (side) {
+                HIP_TRY(hipEventRecord(ctx->ev_a[slot], stream));
+                HIP_TRY(hipStreamWaitEvent(sb, ctx->ev_a[slot], 0));
+            }
 
-            rc = prof_begin(ctx, 1, stream, &ep);
+            rc = prof_begin(ctx, 1, sb, &ep);
             if (rc) return rc;
             if (ctx->opt_stage_b == 1) {
                 const int64_t rows = jn * n;
-                launch_b_mfma(st->cp / 16, (unsigned)((rows + 63) / 64), stream, yprime, rows, ldy, st->dev, djb + j0, n, m, out);
+                launch_b_mfma(st->cp / 16, (unsigned)((rows + 63) / 64), sb, yprime, rows, ldy, st->dev, djb + j0, n, m, out);
             } else {
-                hipLaunchKernelGGL(stage_b_valu_kernel, dim3((unsigned)jn), dim3(256), 0, stream, yprime, ldy, g.n_cols,
+                hipLaunchKernelGGL(stage_b_valu_kernel, dim3((unsigned)jn), dim3(256), 0, sb, yprime, ldy, g.n_cols,
                                    st->dev, st->cp, djb + j0, n, m, out);
             }
             HIP_TRY(hipGetLastError());
-            rc = prof_end(ep, stream);
+            rc = prof_end(ep, sb);
             if (rc) return rc;
+            if (side) HIP_TRY(hipEventRecord(ctx->ev_b[slot], sb));
+            ++c;
+        }
+        if (side) {  // the caller's stream continues only after every stage B of this group
+            const int64_t used = std::min<int64_t>(c, slots);
+            for (int64_t k = 0; k < used; ++k) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_b[k], 0));
         }
         l0 = l1;
     }

@@ -57,8 +57,8 @@ SUBSET = [c for c in ALL_OK if c['id'].startswith(('two_', 'dom_', 'qdim_', 'con
 
 @pytest.mark.parametrize('opts', [dict(stage_b=0), dict(stage_b=1), dict(a_waves=8, a_unroll=4),
                                   dict(a_waves=16, a_unroll=8), dict(a_waves=4, a_unroll=4),
-                                  dict(workspace_mb=16)],
-                         ids=['valuB', 'mfmaB', 'w8u4', 'w16u8', 'w4u4', 'smallws'])
+                                  dict(workspace_mb=16), dict(a_stagger=1), dict(overlap=1), dict(fuse=0)],
+                         ids=['valuB', 'mfmaB', 'w8u4', 'w16u8', 'w4u4', 'smallws', 'stagger', 'nooverlap', 'nofuse'])
 def test_kernel_variants_agree_with_golden(dd, opts):
     import torch
     ctx = dd.get_context(torch.cuda.current_device())
@@ -265,3 +265,49 @@ def test_api_errors(dd):
         dd.quantize_batch([dd.LayerBatch([x], 3, 80)], bad)
     with pytest.raises(ValueError):
         dd.LayerBatch([x.cpu()], 3, 80)                                  # host memory is refused
+
+
+def test_fused_groups_large_batch(dd):
+    """RecCut-shaped domain lists (parts tiling the protein + whole protein) stream every row once;
+    same int8 as the unfused path and as the oracle, also across chunk boundaries."""
+    import torch
+    rng = np.random.default_rng(11)
+    n_seq, D = 600, 640
+    lens = [int(v) for v in rng.integers(60, 400, size=n_seq)]
+    doms = []
+    for L in lens:
+        k = int(rng.integers(1, 6))
+        if k == 1 or L < 60:
+            doms.append([f'1-{L}'])
+            continue
+        cuts = sorted(set(int(c) // 8 * 8 for c in rng.integers(10, L - 10, size=k - 1)))
+        edges = [0] + cuts + [L]
+        parts = [f'{a + 1}-{b}' for a, b in zip(edges[:-1], edges[1:])]
+        if len(parts) >= 3 and rng.random() < 0.4:          # a discontinuous domain: first + last part
+            parts = [parts[-1] + ',' + parts[0]] + parts[1:-1]
+        doms.append(parts + [f'1-{L}'])
+    xs = [torch.randn((sum(lens), D), device='cuda') * 3 + 1 for _ in range(2)]
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    table = dd.PieceTable(lens, doms)
+    lbs = [dd.LayerBatch(x, 3, 80, row_offsets=offs) for x in xs]
+    ctx = dd.get_context(torch.cuda.current_device())
+    fused = dd.quantize_batch(lbs, table).cpu().numpy()
+    old = {k: ctx.get_option(k) for k in ('fuse', 'workspace_mb')}
+    try:
+        ctx.set_option('fuse', 0)
+        plain = dd.quantize_batch(lbs, table).cpu().numpy()
+        ctx.set_option('fuse', 1)
+        ctx.set_option('workspace_mb', 16)                  # many chunks, groups never split
+        chunked = dd.quantize_batch(lbs, table).cpu().numpy()
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v)
+    np.testing.assert_array_equal(fused, plain)
+    np.testing.assert_array_equal(chunked, plain)
+    row = 0
+    for s in range(0, n_seq, 37):
+        first = table.owner.index(s)
+        a, b = int(offs[s]), int(offs[s]) + lens[s]
+        q = orc.quantize([x[a:b].cpu().numpy() for x in xs], doms[s], [3, 80, 3, 80])
+        for k, key in enumerate(q):
+            np.testing.assert_array_equal(fused[first + k].astype(np.int64), q[key], err_msg=f'seq {s} {key}')
