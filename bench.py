@@ -38,9 +38,12 @@ def parse():
                     help='CPU baseline worker processes (0 = usable cores, at most 16 = one GPU\'s CPU share on the pool)')
     ap.add_argument('--parity-sample', type=int, default=8)
     ap.add_argument('--opt', action='append', default=[], help='name=value passed to dctfp_set_option')
-    ap.add_argument('--workload', choices=['c2', 'c3', 'c4'], default='c2',
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
+                    help='torch.distributed backend for the barrier / max-over-ranks (gloo: rehearsal of N > 1 on one GPU)')
+    ap.add_argument('--workload', choices=['c2', 'c3', 'c4', 'c5'], default='c2',
                     help='c2 = headline (fixed L, whole-sequence domains); c3 = ragged L in [50,2000]; '
-                         'c4 = D=2560, L<=500, several domains per protein + whole protein')
+                         'c4 = D=2560, L<=500, several domains per protein + whole protein; '
+                         'c5 = database-build mix: pfam-like lengths, D=640, RecCut-like domains')
     return ap.parse_args()
 
 
@@ -70,11 +73,15 @@ def make_workload(args, rank, np):
     rng = np.random.default_rng(2024 + rank)
     if args.workload == 'c3':       # BASELINE config 3: ragged lengths, whole-sequence domains
         return rng.integers(50, 2001, size=n_seq).astype(np.int64), None, args.dim
-    # BASELINE config 4 flavour: D = 2560, L <= 500, RecCut-like partitions (+ whole protein when > 1)
-    lengths = rng.integers(100, 501, size=n_seq).astype(np.int64)
+    if args.workload == 'c5':       # BASELINE config 5 flavour: what a database build feeds the path
+        lengths = np.clip(rng.gamma(2.2, 170.0, size=n_seq).astype(np.int64), 81, 1330)
+        dim, target = 640, 110      # esm2_t30 width; RecCut domains are ~100 residues
+    else:                           # BASELINE config 4 flavour: D = 2560, L <= 500, short domains
+        lengths = rng.integers(100, 501, size=n_seq).astype(np.int64)
+        dim, target = 2560, 0
     doms = []
     for L in lengths:
-        k = int(rng.integers(1, 7))
+        k = int(rng.integers(1, 7)) if target == 0 else max(1, int(round(int(L) / target + rng.normal(0, 0.7))))
         k = max(1, min(k, int(L) // 30))
         if k == 1:
             doms.append([f'1-{L}'])
@@ -82,7 +89,7 @@ def make_workload(args, rank, np):
         cuts = np.sort(rng.choice(np.arange(1, int(L) // 25), size=k - 1, replace=False)) * 25
         edges = [0] + [int(c) for c in cuts] + [int(L)]
         doms.append([f'{a + 1}-{b}' for a, b in zip(edges[:-1], edges[1:])] + [f'1-{L}'])
-    return lengths, doms, 2560
+    return lengths, doms, dim
 
 
 def main():
@@ -108,13 +115,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X; the product path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and args.backend != 'gloo':
+        raise SystemExit(f'LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible')
+    dev_index = local_rank % n_dev               # gloo rehearsal: several ranks may share the one GPU
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     import dctdomain_amd as dd
     from dctdomain_amd import dist as ddist
-    ddist.init('nccl', device)      # "nccl" is RCCL on ROCm; used for the barrier + max-over-ranks only
+    ddist.init(args.backend, device)   # "nccl" is RCCL on ROCm; used for the barrier + max-over-ranks only
 
-    ctx = dd.get_context(local_rank)
+    ctx = dd.get_context(dev_index)
     for kv in args.opt:
         k, v = kv.split('=')
         ctx.set_option(k, int(v))
@@ -150,10 +161,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ms_k, n_k = ctx.profile()                       # hipEvent time of stage A / stage B on the launch stream
     ctx.set_option('profile', 0)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = ddist.max_over_ranks(elapsed, device if args.backend == 'nccl' else None)
 
     # ---- parity sample against the oracle (checker only; outside the timed region) ----
     parity = None
@@ -202,7 +210,9 @@ def main():
                 'c3': f'C3: {n_seq} sequences/GPU, L ~ U[50,2000] ({total_rows} rows), D={D}, {args.layers} layers, '
                       f'whole-sequence domains, ragged batch',
                 'c4': f'C4: {n_seq} sequences/GPU, L ~ U[100,500], D={D}, {args.layers} layers, 1-6 domains + whole '
-                      f'protein ({n_fp} fingerprints)'}[args.workload],
+                      f'protein ({n_fp} fingerprints)',
+                'c5': f'C5 mix: {n_seq} sequences/GPU, pfam-like lengths 81-1330, D={D}, {args.layers} layers, '
+                      f'~110-residue domains + whole protein ({n_fp} fingerprints)'}[args.workload],
                        'sequences_per_gpu': n_seq, 'fingerprints_per_gpu': n_fp, 'L': L if args.workload == 'c2' else None,
                        'D': D, 'layers': args.layers, 'sharding': f'seq{world}'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -9,7 +9,7 @@ import threading
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdctfp.so')
+LIB_PATH = os.environ.get('DCTFP_LIBRARY') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdctfp.so')
 RECCUT_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libreccut.so')
 
 DCTFP_OK = 0

@@ -180,6 +180,23 @@ namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// length -> cosine-table offset.  A flat array while the longest domain is moderate, a hash map beyond.
+struct LenTable {
+    static constexpr uint32_t kNone = 0xffffffffu;
+    std::vector<uint32_t> flat;
+    std::unordered_map<uint32_t, uint32_t> map;
+    bool use_flat;
+    explicit LenTable(uint32_t max_len) : use_flat(max_len <= (1u << 22)) {
+        if (use_flat) flat.assign((size_t)max_len + 1, kNone);
+    }
+    bool has(uint32_t len) const { return use_flat ? flat[len] != kNone : map.find(len) != map.end(); }
+    void set(uint32_t len, uint32_t off) {
+        if (use_flat) flat[len] = off;
+        else map[len] = off;
+    }
+    uint32_t operator[](uint32_t len) const { return use_flat ? flat[len] : map.at(len); }
+};
+
 int get_st(dctfp_ctx* ctx, int n_cols, int m, hipStream_t stream, StEntry** out) {
     auto key = std::make_pair(n_cols, m);
     auto it = ctx->st_cache.find(key);
@@ -299,7 +316,10 @@ void launch_combine(int n, unsigned n_w, hipStream_t s, const WJob* wj, const do
 
 template <typename T, int N, int VEC>
 void launch_a_cfg(const AParams& p, int waves, int unroll) {
-    if (waves == 2) {
+    if (waves == 1) {
+        if (unroll == 4) launch_a_impl<T, N, VEC, 1, 4>(p);
+        else launch_a_impl<T, N, VEC, 1, 8>(p);
+    } else if (waves == 2) {
         if (unroll == 4) launch_a_impl<T, N, VEC, 2, 4>(p);
         else launch_a_impl<T, N, VEC, 2, 8>(p);
     } else if (waves == 8) {
@@ -443,8 +463,8 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "stage_b must be 0 or 1");
         ctx->opt_stage_b = value;
     } else if (n == "a_waves") {
-        if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16)
-            return fail(DCTFP_ERR_INVALID, "a_waves must be 0 (auto), 2, 4, 8 or 16");
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
+            return fail(DCTFP_ERR_INVALID, "a_waves must be 0 (auto), 1, 2, 4, 8 or 16");
         ctx->opt_a_waves = value;
     } else if (n == "a_unroll") {
         if (value != 4 && value != 8) return fail(DCTFP_ERR_INVALID, "a_unroll must be 4 or 8");
@@ -539,8 +559,11 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         for (int64_t d = 0; d < n_domains; ++d)
             if (dom_np[d] == 0) return fail(DCTFP_ERR_INVALID, "domain %lld has no piece", (long long)d);
     }
-    uint32_t min_len = 0xffffffffu;
-    for (int64_t d = 0; d < n_domains; ++d) min_len = std::min(min_len, dom_len[d]);
+    uint32_t min_len = 0xffffffffu, max_len_all = 0;
+    for (int64_t d = 0; d < n_domains; ++d) {
+        min_len = std::min(min_len, dom_len[d]);
+        max_len_all = std::max(max_len_all, dom_len[d]);
+    }
 
     for (int32_t l = 0; l < n_layers; ++l) {
         const dctfp_layer& ly = layers[l];
@@ -569,7 +592,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
     // ---- fused groups: consecutive domains of one sequence whose last domain is the whole
     // sequence and whose other domains tile it exactly (RecCut's output shape).  Their rows are
     // streamed once: every part also accumulates the whole-protein coefficients.
-    std::vector<int32_t> grp_start((size_t)n_domains), part_ord((size_t)n_domains, -1);
+    std::vector<int32_t> grp_start((size_t)n_domains), grp_end((size_t)n_domains, -1), part_ord((size_t)n_domains, -1);
     std::vector<uint8_t> is_whole((size_t)n_domains, 0);
     int64_t n_parts_total = 0, n_whole_total = 0;
     for (int64_t d = 0; d < n_domains; ++d) grp_start[d] = (int32_t)d;
@@ -608,6 +631,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 for (int64_t q = d; q < e; ++q) {
                     part_ord[q] = (int32_t)n_parts_total++;
                     grp_start[q] = (int32_t)d;
+                    grp_end[q] = (int32_t)e;
                 }
                 grp_start[e] = (int32_t)d;
                 is_whole[e] = 1;
@@ -653,15 +677,16 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         uint32_t* hlens = (uint32_t*)(h + off_lens);
 
         const bool trivial = (n == 1 || m == 1);  // single resampled value -> 0/0 -> 0
-        std::unordered_map<uint32_t, uint32_t> len_off;
+        // one cosine table per distinct domain length (direct-address lookup: lengths are small)
+        LenTable len_off(max_len_all);
         std::vector<uint32_t> ulen, uoff;
         uint64_t basis_doubles = 0;
         if (!trivial) {
             for (int64_t d = 0; d < n_domains; ++d) {
-                if (len_off.find(dom_len[d]) == len_off.end()) {
+                if (!len_off.has(dom_len[d])) {
                     if (basis_doubles + (uint64_t)dom_len[d] * nk > 0xffffffffu)
                         return fail(DCTFP_ERR_LIMIT, "cosine tables of one call exceed 2^32 entries");
-                    len_off.emplace(dom_len[d], (uint32_t)basis_doubles);
+                    len_off.set(dom_len[d], (uint32_t)basis_doubles);
                     ulen.push_back(dom_len[d]);
                     uoff.push_back((uint32_t)basis_doubles);
                     basis_doubles += (uint64_t)dom_len[d] * nk;
@@ -692,8 +717,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 hja[job].w_basis_off = 0;
                 hja[job].w_ref = nullptr;
                 if (fuse && part_ord[d] >= 0) {
-                    int64_t w = d;
-                    while (!is_whole[w]) ++w;  // the whole-protein domain closes the group
+                    const int64_t w = grp_end[d];  // the whole-protein domain closes the group
                     hja[job].w_slot = (int32_t)((int64_t)li * n_parts_total + part_ord[d]);
                     hja[job].w_basis_off = len_off[dom_len[w]];
                     hja[job].w_ref = ly.seq_data[pieces[dom_first[w]].seq];
