@@ -160,7 +160,7 @@ struct dctfp_ctx {
         }
         return DCTFP_OK;
     }
-    int64_t opt_stage_b = 1, opt_a_waves = 0, opt_a_unroll = 4, opt_profile = 0, opt_ws_mb = 4096, opt_a_stagger = 0;
+    int64_t opt_stage_b = 1, opt_a_waves = 0, opt_a_unroll = 4, opt_profile = 0, opt_ws_mb = 4096;
     DevBuf tables[2];
     Staging staging[2];
     int flip = 0;
@@ -276,7 +276,6 @@ struct AParams {
     int64_t ld;
     int ldy;
     int n_slabs;
-    int stagger;
     unsigned grid;
     hipStream_t stream;
 };
@@ -287,11 +286,11 @@ void launch_a_impl(const AParams& p) {
     if (p.fused)
         hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, true>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
                            p.jobs, p.stream_jobs, p.pieces, p.basis, p.yprime, p.wpart, p.n_cols, p.ld, p.ldy, p.n_slabs,
-                           p.stagger, inv);
+                           inv);
     else
         hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, false>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
                            p.jobs, p.stream_jobs, p.pieces, p.basis, p.yprime, p.wpart, p.n_cols, p.ld, p.ldy, p.n_slabs,
-                           p.stagger, inv);
+                           inv);
 }
 
 template <int N>
@@ -469,8 +468,6 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "a_unroll") {
         if (value != 4 && value != 8) return fail(DCTFP_ERR_INVALID, "a_unroll must be 4 or 8");
         ctx->opt_a_unroll = value;
-    } else if (n == "a_stagger") {
-        ctx->opt_a_stagger = value ? 1 : 0;
     } else if (n == "fuse") {
         ctx->opt_fuse = value ? 1 : 0;
     } else if (n == "overlap") {
@@ -493,7 +490,6 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     if (n == "stage_b") *value = ctx->opt_stage_b;
     else if (n == "a_waves") *value = ctx->opt_a_waves;
     else if (n == "a_unroll") *value = ctx->opt_a_unroll;
-    else if (n == "a_stagger") *value = ctx->opt_a_stagger;
     else if (n == "overlap") *value = ctx->opt_overlap;
     else if (n == "fuse") *value = ctx->opt_fuse;
     else if (n == "profile") *value = ctx->opt_profile;
@@ -877,7 +873,6 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 ap.ld = g.ld;
                 ap.ldy = ldy;
                 ap.n_slabs = n_slabs;
-                ap.stagger = (int)ctx->opt_a_stagger;
                 ap.grid = (unsigned)(ck.sn * n_slabs);
                 ap.stream = stream;
                 int waves = (int)ctx->opt_a_waves;
@@ -1049,8 +1044,10 @@ int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, i
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_TRY(hipSetDevice(ctx->device));
     int32_t max_level = 0;
+    bool vec4 = !square && n_cols % 4 == 0;
     for (int64_t i = 0; i < n_jobs; ++i) {
         const dctfp_stitch_job& j = jobs[i];
+        if (!aligned16(j.src) || !aligned16(j.dst) || (j.ld_src % 4) || (j.ld_dst % 4)) vec4 = false;
         if (!j.src || !j.dst || j.n_rows < 1 || j.n_avg < 0 || j.n_avg > j.n_rows || j.level < 0 ||
             j.ld_src < (square ? j.n_rows : n_cols) || j.ld_dst < (square ? j.n_rows : n_cols))
             return fail(DCTFP_ERR_INVALID, "dctfp_stitch: window %lld is malformed", (long long)i);
@@ -1093,7 +1090,8 @@ int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, i
             const unsigned ny = (unsigned)std::min<int64_t>(cnt - done, 65535);
             dim3 grid((unsigned)((max_rows[(size_t)l] + 15) / 16), ny);
             if (square) hipLaunchKernelGGL(stitch_contacts_kernel, grid, dim3(256), 0, stream, d + start[(size_t)l] + done);
-            else hipLaunchKernelGGL(stitch_rows_kernel, grid, dim3(256), 0, stream, d + start[(size_t)l] + done, n_cols);
+            else if (vec4) hipLaunchKernelGGL((stitch_rows_kernel<true>), grid, dim3(256), 0, stream, d + start[(size_t)l] + done, n_cols);
+            else hipLaunchKernelGGL((stitch_rows_kernel<false>), grid, dim3(256), 0, stream, d + start[(size_t)l] + done, n_cols);
             HIP_TRY(hipGetLastError());
             done += ny;
         }

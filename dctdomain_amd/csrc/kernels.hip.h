@@ -156,8 +156,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
                                                               const PieceA* __restrict__ pieces,
                                                               const double* __restrict__ basis,
                                                               double* __restrict__ yprime, double* __restrict__ wpart,
-                                                              int n_cols, int64_t ld, int ldy, int n_slabs, int stagger,
-                                                              InvTab<N> inv) {
+                                                              int n_cols, int64_t ld, int ldy, int n_slabs, InvTab<N> inv) {
     constexpr int NK = N - 1;
     __shared__ double red[WAVES][NK * VEC][64];
 
@@ -237,14 +236,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
                 row_update(x1, r);
             }
         };
-        // Optional stagger: start each job at a different row group and wrap around, so that the
-        // thousands of resident workgroups do not walk their matrices in lockstep (the sum is the
-        // same set of terms; its rounding order is a fixed function of the job index).
-        uint32_t start = 0;
-        constexpr uint32_t G = UNROLL * WAVES;
-        if (stagger && piece.n_rows >= 2 * G) start = ((job_id * 2654435761u) >> 12) % (piece.n_rows / G) * G;
-        sweep(start, piece.n_rows);
-        if (start) sweep(0, start);
+        sweep(0, piece.n_rows);
     }
 
 #pragma unroll
@@ -708,7 +700,9 @@ struct StitchJob {
     int64_t ld_dst;
 };
 
-// grid.x = row blocks of 16, grid.y = job;  block = 256 threads over the columns
+// grid.x = row blocks of 16, grid.y = job;  block = 256 threads over the columns.
+// VEC4: 16 B per lane when every row of src and dst is 16-byte aligned (checked on the host).
+template <bool VEC4>
 __global__ __launch_bounds__(256) void stitch_rows_kernel(const StitchJob* __restrict__ jobs, int n_cols) {
     const StitchJob job = jobs[blockIdx.y];
     const int r0 = blockIdx.x * 16;
@@ -717,7 +711,20 @@ __global__ __launch_bounds__(256) void stitch_rows_kernel(const StitchJob* __res
     for (int r = r0; r < r1; ++r) {
         const float* __restrict__ s = job.src + (size_t)r * job.ld_src;
         float* __restrict__ d = job.dst + (size_t)r * job.ld_dst;
-        if (r < job.n_avg) {
+        const bool avg = r < job.n_avg;
+        if (VEC4) {
+            const v4f* __restrict__ s4 = reinterpret_cast<const v4f*>(s);
+            v4f* __restrict__ d4 = reinterpret_cast<v4f*>(d);
+            for (int c = threadIdx.x; c < n_cols / 4; c += 256) {
+                const v4f a = s4[c];
+                if (avg) {
+                    const v4f b = d4[c];
+                    d4[c] = (v4f){(b[0] + a[0]) / 2.0f, (b[1] + a[1]) / 2.0f, (b[2] + a[2]) / 2.0f, (b[3] + a[3]) / 2.0f};
+                } else {
+                    d4[c] = a;
+                }
+            }
+        } else if (avg) {
             for (int c = threadIdx.x; c < n_cols; c += 256) d[c] = (d[c] + s[c]) / 2.0f;
         } else {
             for (int c = threadIdx.x; c < n_cols; c += 256) d[c] = s[c];

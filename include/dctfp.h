@@ -172,7 +172,6 @@ int dctfp_block_min(dctfp_ctx* ctx, const int32_t* dist, int64_t ldo, const int6
  *   "stage_b"      0 = plain VALU kernel, 1 = MFMA f64 kernel (default)
  *   "a_waves"      waves per workgroup of the stage-A kernel: 0 = by average rows per job (default), 2, 4, 8, 16
  *   "a_unroll"     rows in flight per wave (4 or 8)
- *   "a_stagger"    1 = every job starts at a different row group (measured: no effect)
  *   "overlap"      sub-chunks of a large batch whose stage B runs on a side stream under the
  *                  next sub-chunk's stage A (1 = off, default 4)
  *   "fuse"         1 (default) = proteins given as parts + whole protein are streamed once

@@ -1,0 +1,41 @@
+"""Kernel-level timings of the "next" rows: stitcher, contact top-k, L1 matrix."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import dctdomain_amd as dd
+from dctdomain_amd import reccut
+from dctdomain_amd.embedding import stitch_embeddings_batch, stitch_contacts_batch
+from dctdomain_amd.similarity import l1_matrix
+dev = torch.device('cuda', 0)
+res = {}
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+# f-1: 2000 sequences of L = 1400 (windows 500,500,500,500), D = 1280
+n, D = 2000, 1280
+wins = [[torch.randn((500, D), device=dev) for _ in range(4)] for _ in range(64)]
+seqw = [wins[i % 64] for i in range(n)]
+t = timeit(lambda: stitch_embeddings_batch(seqw))
+bytes_moved = n * (4 * 500 * D * 4 + 1400 * D * 4 + 3 * 200 * D * 4)       # window reads + output writes + overlap re-reads
+res['stitch_embeddings'] = {'sequences': n, 'ms': round(1e3 * t, 3), 'GBps': round(bytes_moved / t / 1e9), 'note': 'includes python job-table build'}
+cw = [[torch.rand((500, 500), device=dev) for _ in range(4)] for _ in range(64)]
+t = timeit(lambda: stitch_contacts_batch([cw[i % 64] for i in range(256)], 300))
+res['stitch_contacts'] = {'sequences': 256, 'ms': round(1e3 * t, 3), 'us_per_sequence': round(1e6 * t / 256, 1)}
+
+# f-2: top-k over 4096 contact maps of L = 500
+maps = [torch.rand((500, 500), device=dev) for _ in range(64)]
+mm = [maps[i % 64] for i in range(4096)]
+t = timeit(lambda: reccut.top_contacts_batch(mm, 2.6), reps=2)
+res['contact_topk'] = {'proteins': 4096, 'L': 500, 'ms_total': round(1e3 * t, 2), 'us_per_protein': round(1e6 * t / 4096, 1),
+                       'note': 'kernel + D2H + host lexsort; reference writece: 107 ms per protein'}
+
+# f-4: 40k x 40k int8 fingerprints
+a = torch.randint(0, 128, (40000, 480), dtype=torch.int8, device=dev)
+t = timeit(lambda: l1_matrix(a, a), reps=3)
+res['l1_matrix'] = {'shape': '40000 x 40000 x 480', 'ms': round(1e3 * t, 2), 'T_abs_diffs_per_s': round(40000 * 40000 * 480 / t / 1e12, 2)}
+print(json.dumps(res, indent=1))
