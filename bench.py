@@ -38,6 +38,8 @@ def parse():
                     help='CPU baseline worker processes (0 = usable cores, at most 16 = one GPU\'s CPU share on the pool)')
     ap.add_argument('--parity-sample', type=int, default=8)
     ap.add_argument('--opt', action='append', default=[], help='name=value passed to dctfp_set_option')
+    ap.add_argument('--storage', choices=['float32', 'float16', 'bfloat16'], default='float32',
+                    help='storage type of the synthetic embeddings (the headline metric is float32, as the reference)')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
                     help='torch.distributed backend for the barrier / max-over-ranks (gloo: rehearsal of N > 1 on one GPU)')
     ap.add_argument('--workload', choices=['c2', 'c3', 'c4', 'c5'], default='c2',
@@ -136,6 +138,8 @@ def main():
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
     layers = [make_layer(torch, gen, total_rows, D, device) for _ in range(args.layers)]
+    if args.storage != 'float32':
+        layers = [x.to(getattr(torch, args.storage)) for x in layers]
     offs = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
     table = dd.PieceTable.whole_sequences(lengths) if doms is None else dd.PieceTable(lengths, doms)
     lbs = [dd.LayerBatch(x, 3, 80, row_offsets=offs) for x in layers]
@@ -175,7 +179,7 @@ def main():
         bad = checked = 0
         for s in pick:
             a, b = int(offs[s]), int(offs[s] + lengths[s])
-            ls = [x[a:b].cpu().numpy() for x in layers]
+            ls = [x[a:b].float().cpu().numpy() for x in layers]
             dl = [f'1-{int(lengths[s])}'] if doms is None else doms[s]
             q = orc.quantize(ls, dl, [3, 80] * args.layers)
             for k, key in enumerate(q):
@@ -188,7 +192,7 @@ def main():
         value = total_fp / elapsed
         # algorithmic bytes: every embedding row read once per layer + the int8 output;
         # 5,120,480 B per fingerprint at C2
-        batch_bytes = args.layers * total_rows * D * 4 + 240 * args.layers * n_fp
+        batch_bytes = args.layers * total_rows * D * layers[0].element_size() + 240 * args.layers * n_fp
         bytes_per_fp = batch_bytes / n_fp
         a_launch_ms = ms_k[0] / max(1, n_k[0])
         a_bytes = batch_bytes * (args.steps / max(1, n_k[0]))               # units one stage-A launch processes

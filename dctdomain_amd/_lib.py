@@ -22,6 +22,8 @@ DCTFP_MAX_N = 8
 DCTFP_MAX_M = 128
 DCTFP_F32 = 0
 DCTFP_F64 = 1
+DCTFP_F16 = 2
+DCTFP_BF16 = 3
 
 #: numpy image of ``dctfp_piece`` (include/dctfp.h)
 PIECE_DTYPE = np.dtype([('row_start', '<i8'), ('n_rows', '<i4'), ('domain', '<i4'),

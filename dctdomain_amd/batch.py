@@ -22,7 +22,11 @@ def _dtype_code(t: torch.Tensor) -> int:
         return _lib.DCTFP_F32
     if t.dtype == torch.float64:
         return _lib.DCTFP_F64
-    raise TypeError(f'embedding dtype {t.dtype}: use float32 or float64')
+    if t.dtype == torch.float16:
+        return _lib.DCTFP_F16
+    if t.dtype == torch.bfloat16:
+        return _lib.DCTFP_BF16
+    raise TypeError(f'embedding dtype {t.dtype}: use float32, float64, float16 or bfloat16')
 
 
 class PieceTable:

@@ -180,6 +180,8 @@ namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+inline size_t dtype_size(int dtype) { return dtype == DCTFP_F64 ? 8 : (dtype == DCTFP_F32 ? 4 : 2); }
+
 // length -> cosine-table offset.  A flat array while the longest domain is moderate, a hash map beyond.
 struct LenTable {
     static constexpr uint32_t kNone = 0xffffffffu;
@@ -350,6 +352,12 @@ void launch_a(const AParams& p, int dtype, int vec, int n, int waves, int unroll
     if (dtype == DCTFP_F32) {
         if (vec == 4) launch_a_n<float, 4>(p, n, waves, unroll);
         else launch_a_n<float, 1>(p, n, waves, unroll);
+    } else if (dtype == DCTFP_F16) {
+        if (vec == 8) launch_a_n<_Float16, 8>(p, n, waves, unroll);
+        else launch_a_n<_Float16, 1>(p, n, waves, unroll);
+    } else if (dtype == DCTFP_BF16) {
+        if (vec == 8) launch_a_n<bf16_t, 8>(p, n, waves, unroll);
+        else launch_a_n<bf16_t, 1>(p, n, waves, unroll);
     } else {
         if (vec == 2) launch_a_n<double, 2>(p, n, waves, unroll);
         else launch_a_n<double, 1>(p, n, waves, unroll);
@@ -564,7 +572,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
     for (int32_t l = 0; l < n_layers; ++l) {
         const dctfp_layer& ly = layers[l];
         if (!ly.seq_data) return fail(DCTFP_ERR_INVALID, "layer %d: seq_data is NULL", l);
-        if (ly.dtype != DCTFP_F32 && ly.dtype != DCTFP_F64) return fail(DCTFP_ERR_INVALID, "layer %d: dtype %d", l, ly.dtype);
+        if (ly.dtype < DCTFP_F32 || ly.dtype > DCTFP_BF16) return fail(DCTFP_ERR_INVALID, "layer %d: dtype %d", l, ly.dtype);
         if (ly.n_cols <= 0 || ly.ld < ly.n_cols) return fail(DCTFP_ERR_INVALID, "layer %d: n_cols %d ld %lld", l, ly.n_cols, (long long)ly.ld);
         if (ly.n_keep < 1 || ly.m_keep < 1) return fail(DCTFP_ERR_INVALID, "layer %d: qdim (%d, %d)", l, ly.n_keep, ly.m_keep);
         if (ly.n_keep > DCTFP_MAX_N || ly.m_keep > DCTFP_MAX_M)
@@ -648,7 +656,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const int ng = l1 - l0;
         const int n = g.n_keep, m = g.m_keep, nk = n - 1;
         const int64_t n_jobs = (int64_t)ng * n_domains;
-        const size_t esz = g.dtype == DCTFP_F32 ? 4 : 8;
+        const size_t esz = dtype_size(g.dtype);
 
         // staging layout
         const size_t off_jobb = 0;
@@ -736,7 +744,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             for (int32_t s = 0; s < n_seq; ++s)
                 if (seq_rows[s] > 0 && !aligned16(ly.seq_data[s])) vec_ok = false;
         }
-        const int vec_want = g.dtype == DCTFP_F32 ? 4 : 2;
+        const int vec_want = (int)(16 / esz);  // 16 bytes per lane
         if (((size_t)g.ld * esz) % 16 != 0 || g.n_cols % vec_want != 0) vec_ok = false;
         const int vec = vec_ok ? vec_want : 1;
 
@@ -878,6 +886,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 int waves = (int)ctx->opt_a_waves;
                 if (waves == 0) {  // auto: short jobs want more, smaller workgroups per CU
                     waves = avg_rows >= 320 ? 8 : (avg_rows >= 48 ? 4 : 2);
+                    if (vec == 8 && waves > 4) waves = 4;  // 8 channels per lane: keep the LDS reduction buffer small
                 }
                 launch_a(ap, g.dtype, vec, n, waves, (int)ctx->opt_a_unroll);
                 HIP_TRY(hipGetLastError());

@@ -21,6 +21,12 @@ namespace dctfp {
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef unsigned short v8us __attribute__((ext_vector_type(8)));
+
+struct bf16_t {  // storage-only bfloat16 (the upper half of a float32)
+    unsigned short bits;
+};
 
 struct JobA {              // one (layer, domain) matrix of stage A
     uint32_t piece_begin;  // first PieceA of this job
@@ -79,7 +85,7 @@ __global__ void basis_kernel(const uint32_t* __restrict__ lens, const uint32_t* 
 }
 
 // Raw (unconverted) register image of one row segment, so that UNROLL loads can be in
-// flight before the first conversion.
+// flight before the first conversion.  16 bytes per lane: 4 x float32, 2 x float64, 8 x float16 / bfloat16.
 template <typename T, int VEC>
 struct Raw;
 template <>
@@ -90,6 +96,14 @@ template <>
 struct Raw<double, 2> { typedef v2d type; };
 template <>
 struct Raw<double, 1> { typedef double type; };
+template <>
+struct Raw<_Float16, 8> { typedef v8h type; };
+template <>
+struct Raw<_Float16, 1> { typedef _Float16 type; };
+template <>
+struct Raw<bf16_t, 8> { typedef v8us type; };
+template <>
+struct Raw<bf16_t, 1> { typedef unsigned short type; };
 
 // Streaming load: global address space (global_load_*, counted vmcnt waits) + nt policy.
 template <typename T, int VEC>
@@ -98,10 +112,21 @@ __device__ inline typename Raw<T, VEC>::type load_raw(const T* p) {
     typedef const R __attribute__((address_space(1))) * GP;
     return __builtin_nontemporal_load((GP)(uintptr_t)p);
 }
-template <int VEC, typename R>
+// Element v of a raw image as float64 (every storage type converts exactly).
+template <typename T, int VEC, typename R>
 __device__ inline double raw_elem(const R& r, int v) {
-    if constexpr (VEC == 1) return (double)r;
-    else return (double)r[v];
+    if constexpr (sizeof(T) == 2 && !__is_same(T, _Float16)) {  // bf16_t
+        unsigned short b;
+        if constexpr (VEC == 1) b = r;
+        else b = r[v];
+        return (double)__uint_as_float((uint32_t)b << 16);
+    } else if constexpr (__is_same(T, _Float16)) {
+        if constexpr (VEC == 1) return (double)(float)r;
+        else return (double)(float)r[v];
+    } else {
+        if constexpr (VEC == 1) return (double)r;
+        else return (double)r[v];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -186,11 +211,11 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
     {
         auto r0 = load_raw<T, VEC>(reinterpret_cast<const T*>(pc[0].ptr) + colc);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) ref[v] = raw_elem<VEC>(r0, v);
+        for (int v = 0; v < VEC; ++v) ref[v] = raw_elem<T, VEC>(r0, v);
         if (has_w) {
             auto w0 = load_raw<T, VEC>(reinterpret_cast<const T*>(job.w_ref) + colc);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) wref[v] = raw_elem<VEC>(w0, v);
+            for (int v = 0; v < VEC; ++v) wref[v] = raw_elem<T, VEC>(w0, v);
         } else {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) wref[v] = 0.0;
@@ -206,7 +231,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
             const double* __restrict__ c = btp + (size_t)r * NK;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                const double xd = raw_elem<VEC>(x, v);
+                const double xd = raw_elem<T, VEC>(x, v);
                 const double d = xd - ref[v];
 #pragma unroll
                 for (int k = 0; k < NK; ++k) acc[k][v] = fma(c[k], d, acc[k][v]);
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
                 const double* __restrict__ cw = wtp + (size_t)r * NK;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    const double dw = raw_elem<VEC>(x, v) - wref[v];
+                    const double dw = raw_elem<T, VEC>(x, v) - wref[v];
 #pragma unroll
                     for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(cw[k], dw, wacc[FUSED ? k : 0][v]);
                 }

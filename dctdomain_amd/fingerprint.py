@@ -34,8 +34,9 @@ def _device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
-def _to_device_matrix(x, device=None) -> torch.Tensor:
-    """numpy / torch 2-D matrix -> contiguous float32 or float64 tensor on the GPU.
+def _to_device_matrix(x, device=None, keep_half: bool = False) -> torch.Tensor:
+    """numpy / torch 2-D matrix -> contiguous tensor on the GPU in a storage type the kernels read
+    (float32 / float64; float16 / bfloat16 stay as they are for ``quantize`` when ``keep_half``).
     Every dtype the reference accepts is promoted exactly (it computes in float64)."""
     if isinstance(x, torch.Tensor):
         t = x
@@ -47,7 +48,8 @@ def _to_device_matrix(x, device=None) -> torch.Tensor:
     if t.dim() != 2:
         raise ValueError(f'expected a 2-D matrix, got shape {tuple(t.shape)}')
     if t.dtype in (torch.float16, torch.bfloat16):
-        t = t.to(torch.float32)
+        if not keep_half:
+            t = t.to(torch.float32)
     elif t.dtype not in (torch.float32, torch.float64):
         t = t.to(torch.float64)
     if t.device.type != 'cuda':
@@ -174,7 +176,7 @@ class Fingerprint:
             if isinstance(e, torch.Tensor) and e.device.type == 'cuda':
                 device = e.device
                 break
-        mats = [_to_device_matrix(e, device) for e in embeds]
+        mats = [_to_device_matrix(e, device, keep_half=True) for e in embeds]
 
         # layers are grouped while they share the row count (one piece table per group)
         results = []          # per layer: (table, tensor rows, column offset, n*m)

@@ -58,7 +58,7 @@ def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, thres
         if len(d) > 1:
             fp.domains.append(f'1-{n}')                        # src/fingerprint.py:106-107
     keys0 = list(fps[0].embed.keys())
-    mats = [[_to_device_matrix(fp.embed[k]) for fp in fps] for k in keys0]
+    mats = [[_to_device_matrix(fp.embed[k], keep_half=True) for fp in fps] for k in keys0]
     rows = [m.shape[0] for m in mats[0]]
     table = PieceTable(rows, [fp.domains for fp in fps])
     layers = [LayerBatch(mats[i], qdim[2 * i], qdim[2 * i + 1]) for i in range(len(keys0))]

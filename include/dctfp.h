@@ -49,6 +49,8 @@ extern "C" {
 
 #define DCTFP_F32 0
 #define DCTFP_F64 1
+#define DCTFP_F16 2  /* IEEE half; dctfp_quantize only (every storage type is promoted exactly, as the */
+#define DCTFP_BF16 3 /* bfloat16;   reference's float64 promotion does)                                    */
 
 typedef struct dctfp_ctx dctfp_ctx;
 
@@ -58,7 +60,7 @@ typedef struct {
     const void* const* seq_data; /* HOST array [n_seq] of DEVICE pointers */
     int64_t ld;                  /* leading dimension in elements (>= n_cols) */
     int32_t n_cols;              /* D */
-    int32_t dtype;               /* DCTFP_F32 or DCTFP_F64 */
+    int32_t dtype;               /* DCTFP_F32, DCTFP_F64, DCTFP_F16 or DCTFP_BF16 */
     int32_t n_keep;              /* n = qdim[2i]   (src/fingerprint.py:185) */
     int32_t m_keep;              /* m = qdim[2i+1] */
     int32_t out_offset;          /* first column of this layer's n*m block in an output row */

@@ -311,3 +311,34 @@ def test_fused_groups_large_batch(dd):
         q = orc.quantize([x[a:b].cpu().numpy() for x in xs], doms[s], [3, 80, 3, 80])
         for k, key in enumerate(q):
             np.testing.assert_array_equal(fused[first + k].astype(np.int64), q[key], err_msg=f'seq {s} {key}')
+
+
+@pytest.mark.parametrize('tdtype', ['float16', 'bfloat16'])
+def test_half_precision_storage(dd, tdtype):
+    """Embeddings kept in float16 / bfloat16 (a half-precision ESM-2 forward pass) are read natively;
+    the result equals the oracle on the same values promoted to float32 (promotion is exact)."""
+    import torch
+    dt = getattr(torch, tdtype)
+    rng = np.random.default_rng(3)
+    # (7 rows, not 5: bfloat16 makes whole channels constant over a short domain, and at L = 5 the
+    #  reference's pocketfft leaves round-off noise where every other length gives an exact 0/0 -- DESIGN section 2)
+    lens = [7, 64, 158, 500, 333]
+    doms = [['1-7'], ['1-64'], ['1-81', '82-158', '1-158'], ['1-200', '201-330,401-500', '331-400', '1-500'], ['10-300']]
+    for D in (1280, 640, 100):          # 100: not a multiple of 8 -> scalar-load variant
+        xs = [[torch.from_numpy(make_input('esm', L, D, 300 + 7 * k + L)).to(dt).cuda() for L in lens] for k in range(2)]
+        table = dd.PieceTable(lens, doms)
+        out = dd.quantize_batch([dd.LayerBatch(xs[0], 3, 80), dd.LayerBatch(xs[1], 3, 80)], table).cpu().numpy()
+        row = 0
+        for s in range(len(lens)):
+            ls = [xs[k][s].float().cpu().numpy() for k in range(2)]
+            q = orc.quantize(ls, doms[s], [3, 80, 3, 80])
+            for key, exp in q.items():
+                np.testing.assert_array_equal(out[row].astype(np.int64), exp, err_msg=f'{tdtype} D={D} seq {s} {key}')
+                row += 1
+        assert row == table.n_domains
+    # the drop-in class keeps half tensors as they are
+    fp = dd.Fingerprint(pid='h', seq='A' * 158, embed={15: xs[0][2], 21: xs[1][2]}, domains=list(doms[2]))
+    fp.quantize([3, 80, 3, 80])
+    q = orc.quantize([xs[0][2].float().cpu().numpy(), xs[1][2].float().cpu().numpy()], doms[2], [3, 80, 3, 80])
+    for k in q:
+        np.testing.assert_array_equal(fp.quants[k], q[k])
