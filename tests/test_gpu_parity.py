@@ -342,3 +342,46 @@ def test_half_precision_storage(dd, tdtype):
     q = orc.quantize([xs[0][2].float().cpu().numpy(), xs[1][2].float().cpu().numpy()], doms[2], [3, 80, 3, 80])
     for k in q:
         np.testing.assert_array_equal(fp.quants[k], q[k])
+
+
+def test_extremes(dd):
+    """Empty inputs, one very long domain, many layers with mixed qdim, a batch of minimal domains."""
+    import torch
+    # nothing to do
+    t0 = dd.PieceTable([10], [['11-20']])
+    assert t0.n_domains == 0
+    x = torch.zeros((10, 128), device='cuda')
+    out = dd.quantize_batch([dd.LayerBatch([x], 3, 80)], t0)
+    assert out.shape == (0, 240)
+    fp = dd.Fingerprint(pid='e', seq='A' * 10, embed={0: x}, domains=['11-20', '0-5'])
+    fp.quantize([3, 80])
+    assert fp.quants == {} and fp.domains == []
+    # a 30 000-row domain (titin-sized), against the closed-form oracle
+    L, D = 30000, 128
+    xl = make_input('esm', L, D, 31337)
+    q = orc.quantize_matrix([xl], [f'1-{L}', f'2-{L - 1}'], [3, 80])
+    fpl = dd.Fingerprint(pid='t', seq='A' * L, embed={0: xl}, domains=[f'1-{L}', f'2-{L - 1}'])
+    fpl.quantize([3, 80])
+    for k in q:
+        np.testing.assert_array_equal(fpl.quants[k], q[k])
+    # five layers, mixed qdim and widths, float64 + float32 storage
+    Ls = 77
+    mats = {0: make_input('esm', Ls, 640, 1), 1: make_input('gauss', Ls, 640, 2).astype(np.float64),
+            2: make_input('esm', Ls, 200, 3), 3: make_input('contact', Ls, Ls, 4), 4: make_input('smooth', Ls, 1280, 5)}
+    qd = [3, 80, 5, 44, 2, 100, 4, 64, 8, 128]
+    doms = ['1-77', '1-30,41-77', '31-40']
+    fp5 = dd.Fingerprint(pid='m', seq='A' * Ls, embed=mats, domains=list(doms))
+    fp5.quantize(qd)
+    q5 = orc.quantize([np.asarray(v) for v in mats.values()], doms, qd)
+    assert list(fp5.quants) == list(q5)
+    for k in q5:
+        np.testing.assert_array_equal(fp5.quants[k], q5[k], err_msg=k)
+    # 20 000 minimal domains (3 rows each) in one call
+    n = 20000
+    big = torch.from_numpy(make_input('gauss', 3 * n, 96, 77)).cuda()
+    tb = dd.PieceTable.whole_sequences([3] * n)
+    ob = dd.quantize_batch([dd.LayerBatch(big, 3, 80, row_offsets=np.arange(n) * 3)], tb).cpu().numpy()
+    host = big.cpu().numpy()
+    for s in (0, 1, 9999, 19999):
+        qs = orc.quantize([host[3 * s:3 * s + 3]], ['1-3'], [3, 80])['1-3']
+        np.testing.assert_array_equal(ob[s].astype(np.int64), qs)
