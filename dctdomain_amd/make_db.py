@@ -51,7 +51,7 @@ def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, thres
         return fps
     lens = [len(fp.seq) for fp in fps]
     maps = [reccut._contact_tensor(fp.contacts, n) for fp, n in zip(fps, lens)]
-    offs, ci, cj, cv = reccut.top_contacts_batch(maps, threshold)
+    offs, ci, cj, cv = reccut.top_contacts_batch(maps, threshold, sort=False)
     doms = reccut.domains_from_contacts(lens, offs, ci, cj, cv, threads=max(1, threads))
     for fp, d, n in zip(fps, doms, lens):
         fp.domains.extend(d)

@@ -40,10 +40,10 @@ def _contact_tensor(contacts, n_res: int, device=None) -> torch.Tensor:
     return t
 
 
-def top_contacts_batch(maps: Sequence[torch.Tensor], t: float):
+def top_contacts_batch(maps: Sequence[torch.Tensor], t: float, sort: bool = True):
     """Top ``int(t*L)`` contacts of each map.  Returns (offs, i, j, v) as numpy arrays: protein
-    p's contacts are ``[offs[p], offs[p+1])``, sorted by (-v, i, j) -- the order of the
-    reference's CON line."""
+    p's contacts are ``[offs[p], offs[p+1])``; with ``sort`` they are ordered by (-v, i, j) -- the
+    order of the reference's CON line (the domain cutter itself does not care about the order)."""
     n = len(maps)
     if n == 0:
         return np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
@@ -67,7 +67,7 @@ def top_contacts_batch(maps: Sequence[torch.Tensor], t: float):
                                       C.c_void_p(stream.cuda_stream)))
     hi, hj, hv = oi[:total].cpu().numpy(), oj[:total].cpu().numpy(), ov[:total].cpu().numpy()
     assert (on.cpu().numpy() == counts).all()
-    for p in range(n):
+    for p in range(n if sort else 0):
         a, b = offs[p], offs[p + 1]
         order = np.lexsort((hj[a:b], hi[a:b], -hv[a:b].astype(np.float64)))
         hi[a:b], hj[a:b], hv[a:b] = hi[a:b][order], hj[a:b][order], hv[a:b][order]
@@ -128,5 +128,5 @@ def predict_domains(fp, threshold: float) -> List[str]:
     trailing whole-protein entry (the caller adds it when there are several domains)."""
     slen = len(fp.seq)
     cmap = _contact_tensor(fp.contacts, slen)
-    offs, ci, cj, cv = top_contacts_batch([cmap], threshold)
+    offs, ci, cj, cv = top_contacts_batch([cmap], threshold, sort=False)
     return domains_from_contacts([slen], offs, ci, cj, cv)[0]
