@@ -165,7 +165,6 @@ struct dctfp_ctx {
     Staging staging[2];
     int flip = 0;
     DevBuf ws;       // yprime
-    DevBuf wpart;    // whole-protein partial slabs of fused groups
     int64_t opt_fuse = 1;
     DevBuf scratch;  // generic idct_quant fs
     std::map<std::pair<int, int>, StEntry> st_cache;
@@ -268,8 +267,7 @@ InvTab<N> make_inv() {
 
 struct AParams {
     const JobA* jobs;
-    const uint32_t* stream_jobs;
-    double* wpart;
+    const Walk* walks;
     bool fused;
     const PieceA* pieces;
     const double* basis;
@@ -287,32 +285,10 @@ void launch_a_impl(const AParams& p) {
     static const InvTab<N> inv = make_inv<N>();
     if (p.fused)
         hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, true>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
-                           p.jobs, p.stream_jobs, p.pieces, p.basis, p.yprime, p.wpart, p.n_cols, p.ld, p.ldy, p.n_slabs,
-                           inv);
+                           p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.n_cols, p.ld, p.ldy, p.n_slabs, inv);
     else
         hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, false>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
-                           p.jobs, p.stream_jobs, p.pieces, p.basis, p.yprime, p.wpart, p.n_cols, p.ld, p.ldy, p.n_slabs,
-                           inv);
-}
-
-template <int N>
-void launch_combine_n(unsigned n_w, hipStream_t s, const WJob* wj, const double* wpart, double* yprime, int n_cols, int ldy) {
-    static const InvTab<N> inv = make_inv<N>();
-    hipLaunchKernelGGL((stage_a_combine_kernel<N>), dim3((unsigned)((ldy + 255) / 256), n_w), dim3(256), 0, s, wj, wpart,
-                       yprime, n_cols, ldy, inv);
-}
-
-void launch_combine(int n, unsigned n_w, hipStream_t s, const WJob* wj, const double* wpart, double* yprime, int n_cols,
-                    int ldy) {
-    switch (n) {
-        case 2: launch_combine_n<2>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
-        case 3: launch_combine_n<3>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
-        case 4: launch_combine_n<4>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
-        case 5: launch_combine_n<5>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
-        case 6: launch_combine_n<6>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
-        case 7: launch_combine_n<7>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
-        default: launch_combine_n<8>(n_w, s, wj, wpart, yprime, n_cols, ldy); break;
-    }
+                           p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.n_cols, p.ld, p.ldy, p.n_slabs, inv);
 }
 
 template <typename T, int N, int VEC>
@@ -445,7 +421,6 @@ int dctfp_destroy(dctfp_ctx* ctx) {
     for (auto& t : ctx->tables) t.release();
     for (auto& s : ctx->staging) s.release();
     ctx->ws.release();
-    ctx->wpart.release();
     ctx->scratch.release();
     for (auto& kv : ctx->st_cache) (void)hipFree(kv.second.dev);
     for (auto& e : ctx->events) {
@@ -596,9 +571,9 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
     // ---- fused groups: consecutive domains of one sequence whose last domain is the whole
     // sequence and whose other domains tile it exactly (RecCut's output shape).  Their rows are
     // streamed once: every part also accumulates the whole-protein coefficients.
-    std::vector<int32_t> grp_start((size_t)n_domains), grp_end((size_t)n_domains, -1), part_ord((size_t)n_domains, -1);
+    std::vector<int32_t> grp_start((size_t)n_domains), grp_end((size_t)n_domains, -1);
     std::vector<uint8_t> is_whole((size_t)n_domains, 0);
-    int64_t n_parts_total = 0, n_whole_total = 0;
+    int64_t n_groups = 0;
     for (int64_t d = 0; d < n_domains; ++d) grp_start[d] = (int32_t)d;
     if (ctx->opt_fuse) {
         std::vector<std::pair<int64_t, int64_t>> runs;  // scratch: (row_start, n_rows) of the parts
@@ -632,14 +607,12 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 ok = ok && pos == seq_rows[s0];
             }
             if (ok) {
-                for (int64_t q = d; q < e; ++q) {
-                    part_ord[q] = (int32_t)n_parts_total++;
+                for (int64_t q = d; q <= e; ++q) {
                     grp_start[q] = (int32_t)d;
                     grp_end[q] = (int32_t)e;
                 }
-                grp_start[e] = (int32_t)d;
                 is_whole[e] = 1;
-                ++n_whole_total;
+                ++n_groups;
             }
             d = e + 1;
         }
@@ -662,9 +635,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const size_t off_jobb = 0;
         const size_t off_joba = align_up(off_jobb + (size_t)n_jobs * sizeof(JobB), 16);
         const size_t off_piece = align_up(off_joba + (size_t)n_jobs * sizeof(JobA), 16);
-        const size_t off_stream = align_up(off_piece + (size_t)ng * n_pieces * sizeof(PieceA), 16);
-        const size_t off_wjob = align_up(off_stream + (size_t)n_jobs * sizeof(uint32_t), 16);
-        const size_t off_lens = align_up(off_wjob + (size_t)ng * n_whole_total * sizeof(WJob), 16);
+        const size_t off_walk = align_up(off_piece + (size_t)ng * n_pieces * sizeof(PieceA), 16);
+        const size_t off_lens = align_up(off_walk + (size_t)n_jobs * sizeof(Walk), 16);
         Staging& stg = ctx->staging[ctx->flip];
         DevBuf& tab = ctx->tables[ctx->flip];
         ctx->flip ^= 1;
@@ -676,8 +648,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         JobB* hjb = (JobB*)(h + off_jobb);
         JobA* hja = (JobA*)(h + off_joba);
         PieceA* hpc = (PieceA*)(h + off_piece);
-        uint32_t* hstream = (uint32_t*)(h + off_stream);
-        WJob* hwj = (WJob*)(h + off_wjob);
+        Walk* hwalk = (Walk*)(h + off_walk);
         uint32_t* hlens = (uint32_t*)(h + off_lens);
 
         const bool trivial = (n == 1 || m == 1);  // single resampled value -> 0/0 -> 0
@@ -704,9 +675,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             hoffs[i] = uoff[i];
         }
         const int ldy_pre = (int)align_up((size_t)g.n_cols, 32);
-        const size_t wpart_bytes = (size_t)ng * n_parts_total * nk * ldy_pre * sizeof(double);
-        const bool fuse = !trivial && n_parts_total > 0 && wpart_bytes <= ((size_t)ctx->opt_ws_mb << 20) &&
-                          (int64_t)ng * n_parts_total < 0x7fffffff;
+        const bool fuse = !trivial && n_groups > 0;
         bool vec_ok = true;
         for (int li = 0; li < ng; ++li) {
             const dctfp_layer& ly = layers[l0 + li];
@@ -717,12 +686,11 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 hja[job].n_pieces = dom_np[d];
                 hja[job].n_rows = dom_len[d];
                 hja[job].basis_off = trivial ? 0u : len_off[dom_len[d]];
-                hja[job].w_slot = -1;
+                hja[job].reserved = 0;
                 hja[job].w_basis_off = 0;
                 hja[job].w_ref = nullptr;
-                if (fuse && part_ord[d] >= 0) {
+                if (fuse && grp_end[d] >= 0 && !is_whole[d]) {
                     const int64_t w = grp_end[d];  // the whole-protein domain closes the group
-                    hja[job].w_slot = (int32_t)((int64_t)li * n_parts_total + part_ord[d]);
                     hja[job].w_basis_off = len_off[dom_len[w]];
                     hja[job].w_ref = ly.seq_data[pieces[dom_first[w]].seq];
                 }
@@ -750,7 +718,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
 
         // ---- chunk plan.  The float64 scratch is a ring of `slots` regions of `sub` jobs each;
         // a chunk never splits a fused group (its whole-protein job needs every part's slab).
-        struct Chunk { int64_t j0, j1, s0, sn, w0, wn; };
+        struct Chunk { int64_t j0, j1, w0, wn; };
         int64_t avg_rows = 0;  // rows per streamed job (launch-shape heuristic)
         {
             int64_t rows = 0, cnt = 0;
@@ -777,27 +745,29 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             if (fuse)
                 for (int64_t d = 0; d < n_domains; ++d) max_group = std::max<int64_t>(max_group, d - grp_start[d] + 1);
             sub = std::max<int64_t>(sub, max_group);  // a group always fits one region
-            int64_t ns = 0, nw = 0;
+            int64_t nw = 0;
             for (int64_t j0 = 0; j0 < n_jobs;) {
                 int64_t j1 = std::min<int64_t>(j0 + sub, n_jobs);
                 if (fuse && j1 < n_jobs) {
                     const int64_t d = j1 % n_domains;
                     if (d != 0 && grp_start[d] < d) j1 -= d - grp_start[d];  // back to the group's first job
                 }
-                Chunk ck{j0, j1, ns, 0, nw, 0};
-                for (int64_t j = j0; j < j1; ++j) {
-                    const int64_t li = j / n_domains, d = j % n_domains;
-                    if (fuse && is_whole[d]) {
-                        WJob& wj = hwj[nw++];
-                        wj.job = (uint32_t)(j - j0);
-                        wj.slot_begin = (uint32_t)(li * n_parts_total + part_ord[grp_start[d]]);
-                        wj.n_parts = (uint32_t)(d - grp_start[d]);
-                        wj.reserved = 0;
-                        ++ck.wn;
+                Chunk ck{j0, j1, nw, 0};
+                for (int64_t j = j0; j < j1;) {
+                    const int64_t d = j % n_domains;
+                    Walk& wk = hwalk[nw++];
+                    wk.job_begin = (uint32_t)(j - j0);
+                    wk.reserved = 0;
+                    if (fuse && grp_end[d] >= 0) {  // d is the first part of a fused group
+                        wk.n_parts = (uint32_t)(grp_end[d] - d);
+                        wk.whole_job = (int32_t)(j - j0 + (grp_end[d] - d));
+                        j += grp_end[d] - d + 1;
                     } else {
-                        hstream[ns++] = (uint32_t)(j - j0);
-                        ++ck.sn;
+                        wk.n_parts = 1;
+                        wk.whole_job = -1;
+                        j += 1;
                     }
+                    ++ck.wn;
                 }
                 plan.push_back(ck);
                 j0 = j1;
@@ -815,8 +785,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const JobB* djb = (const JobB*)(dt + off_jobb);
         const JobA* dja = (const JobA*)(dt + off_joba);
         const PieceA* dpc = (const PieceA*)(dt + off_piece);
-        const uint32_t* dstream = (const uint32_t*)(dt + off_stream);
-        const WJob* dwj = (const WJob*)(dt + off_wjob);
+        const Walk* dwalk = (const Walk*)(dt + off_walk);
         const uint32_t* dlens = (const uint32_t*)(dt + off_lens);
         const uint32_t* doffs = dlens + nu;
         double* dbasis = (double*)(dt + off_basis);
@@ -848,10 +817,6 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         if (ldy != ldy_pre) return fail(DCTFP_ERR_INVALID, "internal: basis width mismatch");
         rc = ctx->ws.ensure((size_t)sub * slots * job_bytes);
         if (rc) return rc;
-        if (fuse) {
-            rc = ctx->wpart.ensure(wpart_bytes);
-            if (rc) return rc;
-        }
         const bool side = slots > 1;
         if (side) {
             rc = ctx->ensure_side();
@@ -868,11 +833,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             EventPair* ep = nullptr;
             rc = prof_begin(ctx, 0, stream, &ep);
             if (rc) return rc;
-            if (ck.sn > 0) {
+            {
                 AParams ap;
                 ap.jobs = dja + j0;
-                ap.stream_jobs = dstream + ck.s0;
-                ap.wpart = (double*)ctx->wpart.p;
+                ap.walks = dwalk + ck.w0;
                 ap.fused = fuse;
                 ap.pieces = dpc;
                 ap.basis = dbasis;
@@ -881,22 +845,15 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 ap.ld = g.ld;
                 ap.ldy = ldy;
                 ap.n_slabs = n_slabs;
-                ap.grid = (unsigned)(ck.sn * n_slabs);
+                ap.grid = (unsigned)(ck.wn * n_slabs);
                 ap.stream = stream;
                 int waves = (int)ctx->opt_a_waves;
-                if (waves == 0) {  // auto: short jobs want more, smaller workgroups per CU
-                    waves = avg_rows >= 320 ? 8 : (avg_rows >= 48 ? 4 : 2);
+                if (waves == 0) {  // auto: short walks want more, smaller workgroups per CU
+                    waves = avg_rows >= 320 ? 8 : (avg_rows >= 160 ? 4 : 2);
                     if (vec == 8 && waves > 4) waves = 4;  // 8 channels per lane: keep the LDS reduction buffer small
                 }
                 launch_a(ap, g.dtype, vec, n, waves, (int)ctx->opt_a_unroll);
                 HIP_TRY(hipGetLastError());
-            }
-            if (ck.wn > 0) {
-                for (int64_t w = 0; w < ck.wn; w += 65535) {
-                    const unsigned nw = (unsigned)std::min<int64_t>(65535, ck.wn - w);
-                    launch_combine(n, nw, stream, dwj + ck.w0 + w, (const double*)ctx->wpart.p, yprime, g.n_cols, ldy);
-                    HIP_TRY(hipGetLastError());
-                }
             }
             rc = prof_end(ep, stream);
             if (rc) return rc;

@@ -34,7 +34,7 @@ struct JobA {              // one (layer, domain) matrix of stage A
     uint32_t n_rows;       // L_d
     uint32_t basis_off;    // offset (doubles) of this length's cosine table
     uint32_t w_basis_off;  // fused groups: cosine table of the whole protein ...
-    int32_t w_slot;        // ... partial slab this part writes (-1: not a part of a fused group)
+    uint32_t reserved;
     const void* w_ref;     // ... and the whole protein's first row
 };
 
@@ -162,177 +162,142 @@ __device__ inline void finish_channel(const double (&f)[N > 1 ? N - 1 : 1], cons
 
 // ---------------------------------------------------------------------------
 // K1: stage A -- HBM-streaming L-axis contraction + per-channel min-max scale.
-//   grid  : n_stream * n_slabs workgroups; workgroup = (job, slab of 64*VEC channels),
-//           job = stream_jobs[blockIdx.x / n_slabs]
+//   grid  : n_walks * n_slabs workgroups; workgroup = (walk, slab of 64*VEC channels).
+//           A walk is a run of consecutive jobs streamed one after the other by the same
+//           workgroup: a single job, or -- FUSED -- the parts of a protein whose parts tile it
+//           exactly and whose last domain is the whole protein (what RecCut emits,
+//           src/fingerprint.py:103-107).  While the parts stream by, a second accumulator set
+//           (the whole protein's cosine table and first row) collects the whole-protein
+//           coefficients, so every embedding row is read once instead of twice.
 //   block : WAVES waves; wave w streams rows w, w+WAVES, ... of every piece of the job,
 //           UNROLL rows (UNROLL x 16 B per lane) in flight; the cosines of a row are
 //           wave-uniform and come through the scalar cache (s_load) into SGPR operands.
 //   out   : yprime[(job*N + j) * ldy + col]  float64, j < N (padding columns = 0)
-//   FUSED : a job with w_slot >= 0 is one part of a protein whose parts tile it exactly and
-//           whose last domain is the whole protein (what RecCut emits, src/fingerprint.py:103-107).
-//           Its rows then also feed the whole-protein coefficients (second accumulator set,
-//           the whole protein's cosine table and first row), written as a partial slab
-//           wpart[w_slot][k][col]; stage_a_combine_kernel adds the parts in domain order.
-//           Every embedding row is thus read once instead of twice.
 // ---------------------------------------------------------------------------
+struct Walk {
+    uint32_t job_begin;  // first job (chunk relative)
+    uint32_t n_parts;    // consecutive jobs streamed by this workgroup
+    int32_t whole_job;   // FUSED: the whole-protein job all parts feed (chunk relative), else -1
+    uint32_t reserved;
+};
+
 template <typename T, int N, int VEC, int WAVES, int UNROLL, bool FUSED>
 __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restrict__ jobs,
-                                                              const uint32_t* __restrict__ stream_jobs,
+                                                              const Walk* __restrict__ walks,
                                                               const PieceA* __restrict__ pieces,
                                                               const double* __restrict__ basis,
-                                                              double* __restrict__ yprime, double* __restrict__ wpart,
-                                                              int n_cols, int64_t ld, int ldy, int n_slabs, InvTab<N> inv) {
+                                                              double* __restrict__ yprime, int n_cols, int64_t ld,
+                                                              int ldy, int n_slabs, InvTab<N> inv) {
     constexpr int NK = N - 1;
     __shared__ double red[WAVES][NK * VEC][64];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t job_id = stream_jobs[blockIdx.x / (uint32_t)n_slabs];
+    const Walk wk = walks[blockIdx.x / (uint32_t)n_slabs];
     const int slab = (int)(blockIdx.x % (uint32_t)n_slabs);
-    const JobA job = jobs[job_id];
     const int col0 = (slab * 64 + lane) * VEC;
     const int colc = (col0 < n_cols) ? col0 : 0;  // out-of-range lanes stream column 0 and are discarded
-    const PieceA* __restrict__ pc = pieces + job.piece_begin;
-    const double* __restrict__ bt = basis + job.basis_off;
-    const bool has_w = FUSED && job.w_slot >= 0;
-    const double* __restrict__ wt = basis + job.w_basis_off;
+    const bool has_w = FUSED && wk.whole_job >= 0;
 
-    double acc[NK][VEC];
     double wacc[FUSED ? NK : 1][VEC];
+    double wref[VEC];
 #pragma unroll
-    for (int k = 0; k < NK; ++k)
+    for (int v = 0; v < VEC; ++v) {
+        wref[v] = 0.0;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            acc[k][v] = 0.0;
-            if (FUSED) wacc[FUSED ? k : 0][v] = 0.0;
-        }
-
-    double ref[VEC], wref[VEC];
-    {
-        auto r0 = load_raw<T, VEC>(reinterpret_cast<const T*>(pc[0].ptr) + colc);
+        for (int k = 0; k < (FUSED ? NK : 1); ++k) wacc[k][v] = 0.0;
+    }
+    if (has_w) {
+        auto w0 = load_raw<T, VEC>(reinterpret_cast<const T*>(jobs[wk.job_begin].w_ref) + colc);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) ref[v] = raw_elem<T, VEC>(r0, v);
-        if (has_w) {
-            auto w0 = load_raw<T, VEC>(reinterpret_cast<const T*>(job.w_ref) + colc);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) wref[v] = raw_elem<T, VEC>(w0, v);
-        } else {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) wref[v] = 0.0;
-        }
+        for (int v = 0; v < VEC; ++v) wref[v] = raw_elem<T, VEC>(w0, v);
     }
 
-    for (uint32_t p = 0; p < job.n_pieces; ++p) {
-        const PieceA piece = pc[p];
-        const T* __restrict__ base = reinterpret_cast<const T*>(piece.ptr) + colc;
-        const double* __restrict__ btp = bt + (size_t)piece.t0 * NK;
-        const double* __restrict__ wtp = wt + (size_t)piece.w0 * NK;
-        auto row_update = [&](const typename Raw<T, VEC>::type& x, uint32_t r) {
-            const double* __restrict__ c = btp + (size_t)r * NK;
+    // LDS combine of the waves' partial sums in a fixed order + the per-channel epilogue
+    auto finish_job = [&](const double (&part)[FUSED ? NK : NK][VEC], uint32_t job_id, bool first) {
+        if (!first) __syncthreads();  // the previous epilogue has finished reading `red`
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const double xd = raw_elem<T, VEC>(x, v);
-                const double d = xd - ref[v];
+        for (int k = 0; k < NK; ++k)
 #pragma unroll
-                for (int k = 0; k < NK; ++k) acc[k][v] = fma(c[k], d, acc[k][v]);
+            for (int v = 0; v < VEC; ++v) red[wave][k * VEC + v][lane] = part[k][v];
+        __syncthreads();
+        for (int cl = threadIdx.x; cl < 64 * VEC; cl += WAVES * 64) {
+            const int ln = cl / VEC, v = cl % VEC;
+            const int col = slab * 64 * VEC + cl;
+            if (col >= ldy) continue;
+            double f[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                double s = red[0][k * VEC + v][ln];
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) s += red[w][k * VEC + v][ln];
+                f[k] = s;
             }
-            if (FUSED && has_w) {
-                const double* __restrict__ cw = wtp + (size_t)r * NK;
+            finish_channel<N>(f, inv, yprime + (size_t)job_id * N * ldy + col, ldy, col >= n_cols);
+        }
+    };
+
+    for (uint32_t part = 0; part < wk.n_parts; ++part) {
+        const uint32_t job_id = wk.job_begin + part;
+        const JobA job = jobs[job_id];
+        const PieceA* __restrict__ pc = pieces + job.piece_begin;
+        const double* __restrict__ bt = basis + job.basis_off;
+        const double* __restrict__ wt = basis + job.w_basis_off;
+
+        double acc[NK][VEC];
+        double ref[VEC];
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[k][v] = 0.0;
+        {
+            auto r0 = load_raw<T, VEC>(reinterpret_cast<const T*>(pc[0].ptr) + colc);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) ref[v] = raw_elem<T, VEC>(r0, v);
+        }
+
+        for (uint32_t p = 0; p < job.n_pieces; ++p) {
+            const PieceA piece = pc[p];
+            const T* __restrict__ base = reinterpret_cast<const T*>(piece.ptr) + colc;
+            const double* __restrict__ btp = bt + (size_t)piece.t0 * NK;
+            const double* __restrict__ wtp = wt + (size_t)piece.w0 * NK;
+            auto row_update = [&](const typename Raw<T, VEC>::type& x, uint32_t r) {
+                const double* __restrict__ c = btp + (size_t)r * NK;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    const double dw = raw_elem<T, VEC>(x, v) - wref[v];
+                    const double d = raw_elem<T, VEC>(x, v) - ref[v];
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(cw[k], dw, wacc[FUSED ? k : 0][v]);
+                    for (int k = 0; k < NK; ++k) acc[k][v] = fma(c[k], d, acc[k][v]);
                 }
-            }
-        };
-        // rows [r_begin, r_end) of the piece, this wave's share, UNROLL loads in flight
-        auto sweep = [&](uint32_t r_begin, uint32_t r_end) {
-            uint32_t r = r_begin + (uint32_t)wave;
-            for (; r + (UNROLL - 1) * WAVES < r_end; r += UNROLL * WAVES) {
+                if (FUSED && has_w) {
+                    const double* __restrict__ cw = wtp + (size_t)r * NK;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const double dw = raw_elem<T, VEC>(x, v) - wref[v];
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(cw[k], dw, wacc[FUSED ? k : 0][v]);
+                    }
+                }
+            };
+            // this wave's share of the piece's rows, UNROLL loads in flight
+            uint32_t r = (uint32_t)wave;
+            for (; r + (UNROLL - 1) * WAVES < piece.n_rows; r += UNROLL * WAVES) {
                 typename Raw<T, VEC>::type xv[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) xv[u] = load_raw<T, VEC>(base + (size_t)(r + u * WAVES) * ld);
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) row_update(xv[u], r + u * WAVES);
             }
-            for (; r < r_end; r += WAVES) {
+            for (; r < piece.n_rows; r += WAVES) {
                 auto x1 = load_raw<T, VEC>(base + (size_t)r * ld);
                 row_update(x1, r);
             }
-        };
-        sweep(0, piece.n_rows);
-    }
-
-#pragma unroll
-    for (int k = 0; k < NK; ++k)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) red[wave][k * VEC + v][lane] = acc[k][v];
-    __syncthreads();
-
-    // combine the waves in a fixed order, then the per-channel epilogue
-    for (int cl = threadIdx.x; cl < 64 * VEC; cl += WAVES * 64) {
-        const int ln = cl / VEC, v = cl % VEC;
-        const int col = slab * 64 * VEC + cl;
-        if (col >= ldy) continue;
-        double f[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            double s = red[0][k * VEC + v][ln];
-#pragma unroll
-            for (int w = 1; w < WAVES; ++w) s += red[w][k * VEC + v][ln];
-            f[k] = s;
         }
-        finish_channel<N>(f, inv, yprime + (size_t)job_id * N * ldy + col, ldy, col >= n_cols);
+        finish_job(acc, job_id, part == 0);
     }
-
-    if (FUSED && has_w) {  // the whole-protein partial of this part
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) red[wave][k * VEC + v][lane] = wacc[FUSED ? k : 0][v];
-        __syncthreads();
-        for (int cl = threadIdx.x; cl < 64 * VEC; cl += WAVES * 64) {
-            const int ln = cl / VEC, v = cl % VEC;
-            const int col = slab * 64 * VEC + cl;
-            if (col >= ldy) continue;
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                double s = red[0][k * VEC + v][ln];
-#pragma unroll
-                for (int w = 1; w < WAVES; ++w) s += red[w][k * VEC + v][ln];
-                wpart[((size_t)job.w_slot * NK + k) * ldy + col] = s;
-            }
-        }
+    if constexpr (FUSED) {
+        if (has_w) finish_job(wacc, (uint32_t)wk.whole_job, false);
     }
-}
-
-// Whole-protein jobs of fused groups: add the parts' partial coefficient slabs in domain order
-// (deterministic), then the same per-channel epilogue.  One thread per channel.
-struct WJob {
-    uint32_t job;         // Y' slot of the whole-protein job (chunk relative)
-    uint32_t slot_begin;  // first partial slab
-    uint32_t n_parts;
-    uint32_t reserved;
-};
-
-template <int N>
-__global__ __launch_bounds__(256) void stage_a_combine_kernel(const WJob* __restrict__ wjobs,
-                                                               const double* __restrict__ wpart,
-                                                               double* __restrict__ yprime, int n_cols, int ldy,
-                                                               InvTab<N> inv) {
-    constexpr int NK = N - 1;
-    const WJob wj = wjobs[blockIdx.y];
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= ldy) return;
-    double f[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) f[k] = 0.0;
-    for (uint32_t p = 0; p < wj.n_parts; ++p)
-#pragma unroll
-        for (int k = 0; k < NK; ++k) f[k] += wpart[((size_t)(wj.slot_begin + p) * NK + k) * ldy + col];
-    finish_channel<N>(f, inv, yprime + (size_t)wj.job * N * ldy + col, ldy, col >= n_cols);
 }
 
 // ---------------------------------------------------------------------------
