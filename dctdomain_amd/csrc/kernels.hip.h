@@ -339,23 +339,46 @@ __global__ __launch_bounds__(256) void stage_b_mfma_kernel(const double* __restr
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
 
+    // Software pipeline: the St chunk and the A fragments of step kb+1 are fetched into registers
+    // while the MFMAs of step kb run, so no global-memory latency sits between two barriers.
+    constexpr int PER = (KB * CP / 2 + 255) / 256;  // v2d pieces of an St chunk per thread
+    v2d nxt[PER];
+    auto fetch_st = [&](int kb) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int i = threadIdx.x + e * 256;
+            if (i < KB * CP / 2) {
+                const int kk = i / (CP / 2), cc = (i % (CP / 2)) * 2;
+                nxt[e] = *reinterpret_cast<const v2d*>(st + (size_t)(kb + kk) * CP + cc);
+            }
+        }
+    };
+    fetch_st(0);
+    v4d a0 = *reinterpret_cast<const v4d*>(ap);
+    v4d a1 = *reinterpret_cast<const v4d*>(ap + 16);
     for (int kb = 0; kb < ldy; kb += KB) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < KB * CP / 2; i += 256) {
-            const int kk = i / (CP / 2);
-            const int cc = (i % (CP / 2)) * 2;
-            const v2d v = *reinterpret_cast<const v2d*>(st + (size_t)(kb + kk) * CP + cc);
-            bs[kk][cc] = v[0];
-            bs[kk][cc + 1] = v[1];
+        __syncthreads();  // the MFMAs of the previous step have read bs
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int i = threadIdx.x + e * 256;
+            if (i < KB * CP / 2) {
+                const int kk = i / (CP / 2), cc = (i % (CP / 2)) * 2;
+                bs[kk][cc] = nxt[e][0];
+                bs[kk][cc + 1] = nxt[e][1];
+            }
         }
         __syncthreads();
-        const v4d a0 = *reinterpret_cast<const v4d*>(ap + kb);
-        const v4d a1 = *reinterpret_cast<const v4d*>(ap + kb + 16);
+        const v4d c0 = a0, c1 = a1;
+        if (kb + KB < ldy) {
+            fetch_st(kb + KB);
+            a0 = *reinterpret_cast<const v4d*>(ap + kb + KB);
+            a1 = *reinterpret_cast<const v4d*>(ap + kb + KB + 16);
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double a = q ? a1[r] : a0[r];
+                const double a = q ? c1[r] : c0[r];
                 const int kk = q * 16 + 4 * g + r;
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
