@@ -53,12 +53,15 @@ EXPORTS = ('dctfp_version', 'dctfp_last_error', 'dctfp_create', 'dctfp_destroy',
            'dctfp_contact_count', 'dctfp_stitch', 'dctfp_l1_matrix', 'dctfp_block_min', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile')
 
 
-def load():
-    """Loads libdctfp.so; raises ImportError when it has not been built."""
+def load(path: str = None):
+    """Loads libdctfp.so; raises ImportError when it has not been built.  ``path`` loads another
+    build of the library (A/B experiments, tools/ab_libs.py) without touching the default one."""
     global _lib
     with _lib_lock:
-        if _lib is not None:
+        if path is None and _lib is not None:
             return _lib
+        if path is not None:
+            return _configure(C.CDLL(path))
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f'{LIB_PATH} is missing: build the HIP extension first '
@@ -68,7 +71,13 @@ def load():
         # /opt/rocm.  Loading libdctfp.so before torch would pull the system copies in and leave the
         # process with two HSA runtimes (the second one then sees "no ROCm-capable device").
         import torch  # noqa: F401
-        lib = C.CDLL(LIB_PATH)
+        _lib = _configure(C.CDLL(LIB_PATH))
+        return _lib
+
+
+def _configure(lib):
+    """Declares the argument / result types of every export of include/dctfp.h."""
+    if True:
         lib.dctfp_version.restype = C.c_int
         lib.dctfp_last_error.restype = C.c_char_p
         lib.dctfp_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
@@ -95,7 +104,6 @@ def load():
             if fn not in ('dctfp_last_error', 'dctfp_contact_count'):
                 getattr(lib, fn).restype = C.c_int
         lib.dctfp_contact_count.restype = C.c_int64
-        _lib = lib
         return lib
 
 
@@ -114,8 +122,8 @@ def check(rc: int):
 class Context:
     """One ``dctfp_ctx`` (per process and device)."""
 
-    def __init__(self, device: int):
-        lib = load()
+    def __init__(self, device: int, lib=None):
+        lib = lib if lib is not None else load()
         handle = C.c_void_p()
         check(lib.dctfp_create(int(device), C.byref(handle)))
         self._lib = lib

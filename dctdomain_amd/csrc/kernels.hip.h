@@ -110,7 +110,11 @@ template <typename T, int VEC>
 __device__ inline typename Raw<T, VEC>::type load_raw(const T* p) {
     typedef typename Raw<T, VEC>::type R;
     typedef const R __attribute__((address_space(1))) * GP;
+#ifdef DCTFP_PLAIN_LOADS  // A/B switch (tools/ab_build_run.sh): default cache policy instead of nt
+    return *(GP)(uintptr_t)p;
+#else
     return __builtin_nontemporal_load((GP)(uintptr_t)p);
+#endif
 }
 // Element v of a raw image as float64 (every storage type converts exactly).
 template <typename T, int VEC, typename R>
