@@ -165,7 +165,7 @@ struct dctfp_ctx {
     Staging staging[2];
     int flip = 0;
     DevBuf ws;       // yprime
-    int64_t opt_fuse = 1;
+    int64_t opt_fuse = 1, opt_pack_y = 1;
     DevBuf scratch;  // generic idct_quant fs
     std::map<std::pair<int, int>, StEntry> st_cache;
     uint64_t tick = 0;
@@ -271,7 +271,9 @@ struct AParams {
     bool fused;
     const PieceA* pieces;
     const double* basis;
-    double* yprime;
+    char* yprime;
+    int64_t job_bytes;
+    int packed;
     int n_cols;
     int64_t ld;
     int ldy;
@@ -285,10 +287,12 @@ void launch_a_impl(const AParams& p) {
     static const InvTab<N> inv = make_inv<N>();
     if (p.fused)
         hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, true>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
-                           p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.n_cols, p.ld, p.ldy, p.n_slabs, inv);
+                           p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld, p.ldy, p.n_slabs,
+                           inv);
     else
         hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, false>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
-                           p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.n_cols, p.ld, p.ldy, p.n_slabs, inv);
+                           p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld, p.ldy, p.n_slabs,
+                           inv);
 }
 
 template <typename T, int N, int VEC>
@@ -340,12 +344,16 @@ void launch_a(const AParams& p, int dtype, int vec, int n, int waves, int unroll
     }
 }
 
-void launch_b_mfma(int nt, unsigned grid, hipStream_t s, const double* yp, int64_t rows, int ldy, const double* st,
-                   const JobB* jobs, int n, int m, int8_t* out) {
-#define DCTFP_B_CASE(NT)                                                                                          \
-    case NT:                                                                                                      \
-        hipLaunchKernelGGL((stage_b_mfma_kernel<NT>), dim3(grid), dim3(256), 0, s, yp, rows, ldy, st, jobs, n, m, \
-                           out);                                                                                  \
+void launch_b_mfma(int nt, bool packed, unsigned grid, hipStream_t s, const char* yp, int64_t job_bytes, int64_t rows,
+                   int ldy, const double* st, const JobB* jobs, int n, int m, int8_t* out) {
+#define DCTFP_B_CASE(NT)                                                                                             \
+    case NT:                                                                                                         \
+        if (packed)                                                                                                  \
+            hipLaunchKernelGGL((stage_b_mfma_kernel<NT, true>), dim3(grid), dim3(256), 0, s, yp, job_bytes, rows, ldy, \
+                               st, jobs, n, m, out);                                                                 \
+        else                                                                                                         \
+            hipLaunchKernelGGL((stage_b_mfma_kernel<NT, false>), dim3(grid), dim3(256), 0, s, yp, job_bytes, rows,   \
+                               ldy, st, jobs, n, m, out);                                                            \
         break;
     switch (nt) {
         DCTFP_B_CASE(1)
@@ -356,8 +364,12 @@ void launch_b_mfma(int nt, unsigned grid, hipStream_t s, const double* yp, int64
         DCTFP_B_CASE(6)
         DCTFP_B_CASE(7)
         default:
-            hipLaunchKernelGGL((stage_b_mfma_kernel<8>), dim3(grid), dim3(256), 0, s, yp, rows, ldy, st, jobs, n, m,
-                               out);
+            if (packed)
+                hipLaunchKernelGGL((stage_b_mfma_kernel<8, true>), dim3(grid), dim3(256), 0, s, yp, job_bytes, rows, ldy,
+                                   st, jobs, n, m, out);
+            else
+                hipLaunchKernelGGL((stage_b_mfma_kernel<8, false>), dim3(grid), dim3(256), 0, s, yp, job_bytes, rows, ldy,
+                                   st, jobs, n, m, out);
             break;
     }
 #undef DCTFP_B_CASE
@@ -451,6 +463,8 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "a_unroll") {
         if (value != 4 && value != 8) return fail(DCTFP_ERR_INVALID, "a_unroll must be 4 or 8");
         ctx->opt_a_unroll = value;
+    } else if (n == "pack_y") {
+        ctx->opt_pack_y = value ? 1 : 0;
     } else if (n == "fuse") {
         ctx->opt_fuse = value ? 1 : 0;
     } else if (n == "overlap") {
@@ -475,6 +489,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     else if (n == "a_unroll") *value = ctx->opt_a_unroll;
     else if (n == "overlap") *value = ctx->opt_overlap;
     else if (n == "fuse") *value = ctx->opt_fuse;
+    else if (n == "pack_y") *value = ctx->opt_pack_y;
     else if (n == "profile") *value = ctx->opt_profile;
     else if (n == "workspace_mb") *value = ctx->opt_ws_mb;
     else return fail(DCTFP_ERR_INVALID, "unknown option '%s'", name);
@@ -730,7 +745,9 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             avg_rows = cnt ? rows / cnt : 0;
         }
         std::vector<Chunk> plan;
-        const size_t job_bytes = (size_t)n * ldy_pre * sizeof(double);
+        // Y' per job: n float64 rows, or (n = 3 with the MFMA stage B) one float64 t row + one state byte per channel
+        const bool packed = ctx->opt_pack_y && n == 3 && ctx->opt_stage_b == 1;
+        const size_t job_bytes = packed ? (size_t)ldy_pre * 9 : (size_t)n * ldy_pre * sizeof(double);
         const int n_slabs = (ldy_pre + 64 * vec - 1) / (64 * vec);
         int slots = 1;
         int64_t sub = 1;
@@ -828,7 +845,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         for (const Chunk& ck : plan) {
             const int64_t j0 = ck.j0, jn = ck.j1 - ck.j0;
             const int slot = (int)(c % slots);
-            double* yprime = (double*)((char*)ctx->ws.p + (size_t)slot * sub * job_bytes);
+            char* yprime = (char*)ctx->ws.p + (size_t)slot * sub * job_bytes;
             if (side && c >= slots) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_b[slot], 0));  // slot free again?
             EventPair* ep = nullptr;
             rc = prof_begin(ctx, 0, stream, &ep);
@@ -841,6 +858,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 ap.pieces = dpc;
                 ap.basis = dbasis;
                 ap.yprime = yprime;
+                ap.job_bytes = (int64_t)job_bytes;
+                ap.packed = packed ? 1 : 0;
                 ap.n_cols = g.n_cols;
                 ap.ld = g.ld;
                 ap.ldy = ldy;
@@ -866,9 +885,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             if (rc) return rc;
             if (ctx->opt_stage_b == 1) {
                 const int64_t rows = jn * n;
-                launch_b_mfma(st->cp / 16, (unsigned)((rows + 63) / 64), sb, yprime, rows, ldy, st->dev, djb + j0, n, m, out);
+                launch_b_mfma(st->cp / 16, packed, (unsigned)((rows + 63) / 64), sb, yprime, (int64_t)job_bytes, rows, ldy,
+                              st->dev, djb + j0, n, m, out);
             } else {
-                hipLaunchKernelGGL(stage_b_valu_kernel, dim3((unsigned)jn), dim3(256), 0, sb, yprime, ldy, g.n_cols,
+                hipLaunchKernelGGL(stage_b_valu_kernel, dim3((unsigned)jn), dim3(256), 0, sb, (const double*)yprime, ldy, g.n_cols,
                                    st->dev, st->cp, djb + j0, n, m, out);
             }
             HIP_TRY(hipGetLastError());

@@ -140,7 +140,7 @@ __device__ inline double raw_elem(const R& r, int v) {
 // ---------------------------------------------------------------------------
 template <int N>
 __device__ inline void finish_channel(const double (&f)[N > 1 ? N - 1 : 1], const InvTab<N>& inv, double* __restrict__ o,
-                                      int ldy, bool pad) {
+                                      int ldy, bool pad, bool packed, void* pk) {
     constexpr int NK = N - 1;
     double y[N];
     double mn = INFINITY, mx = -INFINITY;
@@ -156,12 +156,42 @@ __device__ inline void finish_channel(const double (&f)[N > 1 ? N - 1 : 1], cons
         mx = fmax(mx, s);
     }
     const double den = mx - mn;
+    if constexpr (N == 3) {
+        if (packed) {
+            // n = 3: the scaled values of a channel are {0, t, 1} (or NaN); store t once (float64) and a
+            // 2-bit state per row (0 -> 0.0, 1 -> 1.0, 2 -> t, 3 -> NaN): 9 bytes instead of 24.
+            double t = 0.0;
+            unsigned code = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double z = bad ? __builtin_nan("") : (y[j] - mn) / den;
+                unsigned st = 2;
+                if (z != z) st = 3;
+                else if (z == 0.0) st = 0;
+                else if (z == 1.0) st = 1;
+                else t = z;
+                code |= st << (2 * j);
+            }
+            if (pad) {
+                t = 0.0;
+                code = 0;
+            }
+            *o = t;
+            *reinterpret_cast<uint8_t*>(pk) = (uint8_t)code;
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         double z = bad ? __builtin_nan("") : (y[j] - mn) / den;
         if (pad) z = 0.0;
         o[(size_t)j * ldy] = z;
     }
+}
+
+// One value of a packed Y' row: state bits -> 0, 1, t or NaN.
+__device__ inline double unpack_y(unsigned st, double t) {
+    return st == 0 ? 0.0 : (st == 1 ? 1.0 : (st == 2 ? t : __builtin_nan("")));
 }
 
 // ---------------------------------------------------------------------------
@@ -190,8 +220,10 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
                                                               const Walk* __restrict__ walks,
                                                               const PieceA* __restrict__ pieces,
                                                               const double* __restrict__ basis,
-                                                              double* __restrict__ yprime, int n_cols, int64_t ld,
-                                                              int ldy, int n_slabs, InvTab<N> inv) {
+                                                              char* __restrict__ yprime, int64_t job_bytes, int packed,
+                                                              int n_cols, int64_t ld, int ldy, int n_slabs, InvTab<N> inv) {
+    // yprime: per job either N rows of ldy float64, or (packed, N = 3) ldy float64 t values followed by
+    // ldy state bytes (finish_channel)
     constexpr int NK = N - 1;
     __shared__ double red[WAVES][NK * VEC][64];
 
@@ -237,7 +269,9 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
                 for (int w = 1; w < WAVES; ++w) s += red[w][k * VEC + v][ln];
                 f[k] = s;
             }
-            finish_channel<N>(f, inv, yprime + (size_t)job_id * N * ldy + col, ldy, col >= n_cols);
+            char* __restrict__ jb = yprime + (size_t)job_id * job_bytes;
+            finish_channel<N>(f, inv, reinterpret_cast<double*>(jb) + col, ldy, col >= n_cols, packed != 0,
+                              jb + (size_t)ldy * sizeof(double) + col);
         }
     };
 
@@ -321,9 +355,9 @@ __device__ inline int8_t quant127(double num, double den, bool bad) {
 //   f64 MFMA layouts (cdna_hip_programming.md section 3): A[i = l&15][k = l>>4],
 //   B[k = l>>4][j = l&15], C/D reg i: row = (l>>4) + 4 i, col = l & 15.
 // ---------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void stage_b_mfma_kernel(const double* __restrict__ yp, int64_t n_rows_total,
-                                                            int ldy, const double* __restrict__ st,
+template <int NT, bool PACKED>
+__global__ __launch_bounds__(256) void stage_b_mfma_kernel(const char* __restrict__ ypb, int64_t job_bytes,
+                                                            int64_t n_rows_total, int ldy, const double* __restrict__ st,
                                                             const JobB* __restrict__ jobs, int n, int m,
                                                             int8_t* __restrict__ out) {
     constexpr int CP = NT * 16;
@@ -337,7 +371,21 @@ __global__ __launch_bounds__(256) void stage_b_mfma_kernel(const double* __restr
     const int64_t row0 = (int64_t)blockIdx.x * 64 + wave * 16;
     int64_t arow = row0 + r16;
     if (arow >= n_rows_total) arow = n_rows_total - 1;
-    const double* __restrict__ ap = yp + (size_t)arow * ldy + 4 * g;
+    // A operand source: row (job, j) of Y'.  Plain: float64 row.  PACKED (n = 3): the job's t row + state bytes.
+    const int64_t ajob = arow / n;
+    const int aj = (int)(arow - ajob * n);
+    const char* __restrict__ jbase = ypb + (size_t)ajob * job_bytes;
+    const double* __restrict__ ap = reinterpret_cast<const double*>(jbase) + (PACKED ? 0 : (size_t)aj * ldy) + 4 * g;
+    const uint8_t* __restrict__ cp8 = reinterpret_cast<const uint8_t*>(jbase) + (size_t)ldy * sizeof(double) + 4 * g;
+    auto fetch_a = [&](int k) -> v4d {
+        v4d t = *reinterpret_cast<const v4d*>(ap + k);
+        if constexpr (PACKED) {
+            const uint32_t c = *reinterpret_cast<const uint32_t*>(cp8 + k);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = unpack_y((c >> (8 * r + 2 * aj)) & 3u, t[r]);
+        }
+        return t;
+    };
 
     v4d acc[NT];
 #pragma unroll
@@ -358,8 +406,8 @@ __global__ __launch_bounds__(256) void stage_b_mfma_kernel(const double* __restr
         }
     };
     fetch_st(0);
-    v4d a0 = *reinterpret_cast<const v4d*>(ap);
-    v4d a1 = *reinterpret_cast<const v4d*>(ap + 16);
+    v4d a0 = fetch_a(0);
+    v4d a1 = fetch_a(16);
     for (int kb = 0; kb < ldy; kb += KB) {
         __syncthreads();  // the MFMAs of the previous step have read bs
 #pragma unroll
@@ -375,8 +423,8 @@ __global__ __launch_bounds__(256) void stage_b_mfma_kernel(const double* __restr
         const v4d c0 = a0, c1 = a1;
         if (kb + KB < ldy) {
             fetch_st(kb + KB);
-            a0 = *reinterpret_cast<const v4d*>(ap + kb + KB);
-            a1 = *reinterpret_cast<const v4d*>(ap + kb + KB + 16);
+            a0 = fetch_a(kb + KB);
+            a1 = fetch_a(kb + KB + 16);
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {

@@ -176,6 +176,8 @@ int dctfp_block_min(dctfp_ctx* ctx, const int32_t* dist, int64_t ldo, const int6
  *   "a_unroll"     rows in flight per wave (4 or 8)
  *   "overlap"      sub-chunks of a large batch whose stage B runs on a side stream under the
  *                  next sub-chunk's stage A (1 = off, default 4)
+ *   "pack_y"       1 (default) = n = 3: the scratch between the kernels holds {0, t, 1} as one float64 + 2-bit
+ *                  states per channel (9 bytes instead of 24)
  *   "fuse"         1 (default) = proteins given as parts + whole protein are streamed once
  *   "profile"      1 = bracket the kernels with hipEvents (see dctfp_profile)
  *   "workspace_mb" cap of the float64 scratch between the kernels */
