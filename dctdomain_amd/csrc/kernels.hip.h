@@ -355,14 +355,21 @@ __device__ inline int8_t quant127(double num, double den, bool bad) {
 //   f64 MFMA layouts (cdna_hip_programming.md section 3): A[i = l&15][k = l>>4],
 //   B[k = l>>4][j = l&15], C/D reg i: row = (l>>4) + 4 i, col = l & 15.
 // ---------------------------------------------------------------------------
+#ifndef DCTFP_B_MIN_WAVES
+#define DCTFP_B_MIN_WAVES 2  // register budget of stage B as waves per SIMD (A/B: tools/ab_build_run.sh)
+#endif
 template <int NT, bool PACKED>
-__global__ __launch_bounds__(256) void stage_b_mfma_kernel(const char* __restrict__ ypb, int64_t job_bytes,
+__global__ __launch_bounds__(256, DCTFP_B_MIN_WAVES) void stage_b_mfma_kernel(const char* __restrict__ ypb, int64_t job_bytes,
                                                             int64_t n_rows_total, int ldy, const double* __restrict__ st,
                                                             const JobB* __restrict__ jobs, int n, int m,
                                                             int8_t* __restrict__ out) {
     constexpr int CP = NT * 16;
     constexpr int LDS_LD = CP + 4;
-    constexpr int KB = 32;
+#ifndef DCTFP_B_KB
+#define DCTFP_B_KB 32
+#endif
+    constexpr int KB = DCTFP_B_KB;  // K rows of St per LDS stage
+    constexpr int NQ = KB / 16;     // 16-deep A fragments per stage
     __shared__ double bs[KB][LDS_LD];
 
     const int lane = threadIdx.x & 63;
@@ -377,12 +384,24 @@ __global__ __launch_bounds__(256) void stage_b_mfma_kernel(const char* __restric
     const char* __restrict__ jbase = ypb + (size_t)ajob * job_bytes;
     const double* __restrict__ ap = reinterpret_cast<const double*>(jbase) + (PACKED ? 0 : (size_t)aj * ldy) + 4 * g;
     const uint8_t* __restrict__ cp8 = reinterpret_cast<const uint8_t*>(jbase) + (size_t)ldy * sizeof(double) + 4 * g;
-    auto fetch_a = [&](int k) -> v4d {
-        v4d t = *reinterpret_cast<const v4d*>(ap + k);
+    // raw A fragments are fetched one step ahead and decoded only when they are consumed, so the wait for
+    // them sits a whole step (40 MFMAs) after their issue
+    struct RawA {
+        v4d t;
+        uint32_t c;
+    };
+    auto fetch_a = [&](int k) -> RawA {
+        RawA r;
+        r.t = *reinterpret_cast<const v4d*>(ap + k);
+        r.c = 0;
+        if constexpr (PACKED) r.c = *reinterpret_cast<const uint32_t*>(cp8 + k);
+        return r;
+    };
+    auto decode_a = [&](const RawA& r) -> v4d {
+        v4d t = r.t;
         if constexpr (PACKED) {
-            const uint32_t c = *reinterpret_cast<const uint32_t*>(cp8 + k);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = unpack_y((c >> (8 * r + 2 * aj)) & 3u, t[r]);
+            for (int q = 0; q < 4; ++q) t[q] = unpack_y((r.c >> (8 * q + 2 * aj)) & 3u, t[q]);
         }
         return t;
     };
@@ -406,8 +425,9 @@ __global__ __launch_bounds__(256) void stage_b_mfma_kernel(const char* __restric
         }
     };
     fetch_st(0);
-    v4d a0 = fetch_a(0);
-    v4d a1 = fetch_a(16);
+    RawA araw[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) araw[q] = fetch_a(16 * q);
     for (int kb = 0; kb < ldy; kb += KB) {
         __syncthreads();  // the MFMAs of the previous step have read bs
 #pragma unroll
@@ -420,17 +440,19 @@ __global__ __launch_bounds__(256) void stage_b_mfma_kernel(const char* __restric
             }
         }
         __syncthreads();
-        const v4d c0 = a0, c1 = a1;
+        v4d cur[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) cur[q] = decode_a(araw[q]);
         if (kb + KB < ldy) {
             fetch_st(kb + KB);
-            a0 = fetch_a(kb + KB);
-            a1 = fetch_a(kb + KB + 16);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) araw[q] = fetch_a(kb + KB + 16 * q);
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NQ; ++q) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double a = q ? c1[r] : c0[r];
+                const double a = cur[q][r];
                 const int kk = q * 16 + 4 * g + r;
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
