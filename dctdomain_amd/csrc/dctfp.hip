@@ -198,7 +198,7 @@ struct LenTable {
     uint32_t operator[](uint32_t len) const { return use_flat ? flat[len] : map.at(len); }
 };
 
-int get_st(dctfp_ctx* ctx, int n_cols, int m, hipStream_t stream, StEntry** out) {
+int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
     auto key = std::make_pair(n_cols, m);
     auto it = ctx->st_cache.find(key);
     if (it != ctx->st_cache.end()) {
@@ -245,7 +245,6 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, hipStream_t stream, StEntry** out)
         (void)hipFree(e.dev);
         return fail(DCTFP_ERR_HIP, "hipMemcpy(St): %s", hipGetErrorString(err));
     }
-    (void)stream;
     e.last_use = ++ctx->tick;
     auto ins = ctx->st_cache.emplace(key, e);
     *out = &ins.first->second;
@@ -817,7 +816,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         }
 
         StEntry* st = nullptr;
-        rc = get_st(ctx, g.n_cols, m, stream, &st);
+        rc = get_st(ctx, g.n_cols, m, &st);
         if (rc) return rc;
         const int ldy = st->ldy;
 

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
     }
 
     // LDS combine of the waves' partial sums in a fixed order + the per-channel epilogue
-    auto finish_job = [&](const double (&part)[FUSED ? NK : NK][VEC], uint32_t job_id, bool first) {
+    auto finish_job = [&](const double (&part)[NK][VEC], uint32_t job_id, bool first) {
         if (!first) __syncthreads();  // the previous epilogue has finished reading `red`
 #pragma unroll
         for (int k = 0; k < NK; ++k)
