@@ -28,10 +28,23 @@ from typing import Iterable, List, Sequence, Tuple
 import numpy as np
 
 
+_NPY_HEADERS = {}
+
+
 def _npy_bytes(vec: np.ndarray) -> bytes:
-    buf = BytesIO()
-    np.save(buf, vec, allow_pickle=True)
-    return buf.getvalue()
+    """``np.save`` bytes of a 1-D C-contiguous array; the header of a (dtype, shape) is built by
+    numpy once and reused (a million blobs share one header)."""
+    vec = np.ascontiguousarray(vec)
+    key = (vec.dtype.str, vec.shape)
+    head = _NPY_HEADERS.get(key)
+    if head is None:
+        buf = BytesIO()
+        np.save(buf, vec, allow_pickle=True)
+        blob = buf.getvalue()
+        head = blob[:len(blob) - vec.nbytes]
+        _NPY_HEADERS[key] = head
+        return blob
+    return head + vec.tobytes()
 
 
 class Database:
