@@ -50,7 +50,7 @@ _lib_lock = threading.Lock()
 
 EXPORTS = ('dctfp_version', 'dctfp_last_error', 'dctfp_create', 'dctfp_destroy', 'dctfp_quantize',
            'dctfp_idct_quant', 'dctfp_scale', 'dctfp_gather_rows', 'dctfp_contact_topk',
-           'dctfp_contact_count', 'dctfp_stitch', 'dctfp_l1_matrix', 'dctfp_block_min', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile')
+           'dctfp_contact_count', 'dctfp_stitch', 'dctfp_l1_matrix', 'dctfp_block_min', 'dctfp_row_select', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile')
 
 
 def load(path: str = None):
@@ -96,6 +96,8 @@ def _configure(lib):
                                         C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         lib.dctfp_block_min.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dctfp_row_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
         lib.dctfp_stitch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
         lib.dctfp_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.dctfp_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]

@@ -1113,6 +1113,19 @@ int dctfp_block_min(dctfp_ctx* ctx, const int32_t* dist, int64_t ldo, const int6
     return DCTFP_OK;
 }
 
+int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k,
+                     int32_t* out_val, int32_t* out_idx, void* stream_v) {
+    if (!ctx || !dist || !out_val || !out_idx) return fail(DCTFP_ERR_INVALID, "dctfp_row_select: NULL argument");
+    if (n_rows < 0 || n_cols < 1 || ld < n_cols || k < 1 || k > n_cols) return fail(DCTFP_ERR_INVALID, "dctfp_row_select: bad shape");
+    if (n_rows == 0) return DCTFP_OK;
+    if (n_rows > 0x7fffffff) return fail(DCTFP_ERR_LIMIT, "dctfp_row_select: too many rows");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(row_select_kernel, dim3((unsigned)n_rows), dim3(1024), 0, (hipStream_t)stream_v, dist, ld, n_cols, k,
+                       out_val, out_idx);
+    HIP_TRY(hipGetLastError());
+    return DCTFP_OK;
+}
+
 int64_t dctfp_contact_count(int32_t n_res, double t) {
     if (n_res < 6) return 0;
     const int64_t cand = (int64_t)(n_res - 5) * (n_res - 4) / 2;  // pairs with j >= i + 5

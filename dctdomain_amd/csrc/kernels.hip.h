@@ -926,4 +926,81 @@ __global__ void block_min_kernel(const int32_t* __restrict__ dist, int64_t ldo, 
     out_last[t] = last;
 }
 
+
+// ---------------------------------------------------------------------------
+// k smallest entries of every row of an int32 matrix, ties to the lower column (what a flat L1
+// index returns, src/query_db.py:87).  One workgroup per row: 4-pass radix select for the k-th
+// smallest value, collection of everything below it, and an ordered ballot walk for the ties at
+// the threshold.  Output order within a row is unspecified (the host sorts k entries).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void row_select_kernel(const int32_t* __restrict__ dist, int64_t ld, int64_t n_cols,
+                                                           int k, int32_t* __restrict__ out_val,
+                                                           int32_t* __restrict__ out_idx) {
+    __shared__ int hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_need, s_eq, s_cnt;
+    const int32_t* __restrict__ row = dist + (size_t)blockIdx.x * ld;
+    int32_t* __restrict__ ov = out_val + (size_t)blockIdx.x * k;
+    int32_t* __restrict__ oi = out_idx + (size_t)blockIdx.x * k;
+    if (threadIdx.x == 0) {
+        s_prefix = 0;
+        s_need = k;
+        s_cnt = 0;
+        s_eq = 0;
+    }
+    __syncthreads();
+    // order-preserving key, smallest first: flip the sign bit
+    auto key_of = [](int32_t v) -> uint32_t { return (uint32_t)v ^ 0x80000000u; };
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        for (int64_t c = threadIdx.x; c < n_cols; c += blockDim.x) {
+            const uint32_t key = key_of(row[c]);
+            if (shift == 24 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int need = s_need, b = 0;
+            for (; b < 255; ++b) {
+                if (hist[b] >= need) break;
+                need -= hist[b];
+            }
+            s_prefix = prefix | ((uint32_t)b << shift);
+            s_need = need;
+            s_eq = hist[b];
+        }
+        __syncthreads();
+    }
+    const uint32_t thr = s_prefix;
+    const int need_eq = s_need;
+    const bool all_ties = (s_eq == need_eq);
+    for (int64_t c = threadIdx.x; c < n_cols; c += blockDim.x) {
+        const int32_t v = row[c];
+        const uint32_t key = key_of(v);
+        if (key < thr || (all_ties && key == thr)) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            ov[pos] = v;
+            oi[pos] = (int32_t)c;
+        }
+    }
+    __syncthreads();
+    if (!all_ties && threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int base = s_cnt, taken = 0;
+        for (int64_t c0 = 0; c0 < n_cols && taken < need_eq; c0 += 64) {
+            const int64_t c = c0 + lane;
+            const int32_t v = (c < n_cols) ? row[c] : 0;
+            const bool hit = (c < n_cols) && key_of(v) == thr;
+            const unsigned long long m = __ballot(hit);
+            const int before = __popcll(m & ((1ull << lane) - 1ull));
+            if (hit && taken + before < need_eq) {
+                ov[base + taken + before] = v;
+                oi[base + taken + before] = (int32_t)c;
+            }
+            taken += __popcll(m);
+        }
+    }
+}
+
 }  // namespace dctfp

@@ -15,10 +15,9 @@ import os
 from io import BytesIO
 
 import numpy as np
-import torch
 
 from .database import Database
-from .similarity import l1_matrix
+from .similarity import l1_matrix, row_select
 
 
 def _load_all(db: Database):
@@ -34,9 +33,7 @@ def search(query_rows, query_fps, db_rows, db_fps, khits: int):
     all of those ranked by distance (stable) and the first ``khits`` printed (:33-59)."""
     dist = l1_matrix(query_fps, db_fps)                                   # (nq, ndb) int32 on the GPU
     k = min(khits, db_fps.shape[0])
-    order = torch.sort(dist, dim=1, stable=True)
-    dm = order.values[:, :k].cpu().numpy().astype(np.int64)
-    im = order.indices[:, :k].cpu().numpy()
+    dm, im = row_select(dist, k)                                          # k nearest per query fingerprint
     by_pid = {}
     for qi, r in enumerate(query_rows):
         by_pid.setdefault(r[1], []).append(qi)

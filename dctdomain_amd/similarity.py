@@ -59,3 +59,21 @@ def block_min(dist: torch.Tensor, idx_a, idx_b):
                                             ib.data_ptr(), npb, mn.data_ptr(), last.data_ptr(),
                                             C.c_void_p(stream.cuda_stream)))
     return mn.cpu().numpy(), last.cpu().numpy()
+
+
+def row_select(dist: torch.Tensor, k: int):
+    """(values, indices) numpy arrays (n_rows, k): the k smallest entries of each row, ascending, ties
+    to the lower column -- selected on the GPU (``dctfp_row_select``), the k survivors ordered on the host."""
+    n_rows, n_cols = dist.shape
+    k = min(int(k), n_cols)
+    val = torch.empty((n_rows, k), dtype=torch.int32, device=dist.device)
+    idx = torch.empty((n_rows, k), dtype=torch.int32, device=dist.device)
+    if n_rows:
+        ctx = _lib.get_context(dist.device.index)
+        stream = torch.cuda.current_stream(dist.device)
+        _lib.check(ctx._lib.dctfp_row_select(ctx.handle, dist.data_ptr(), n_rows, n_cols,
+                                             dist.stride(0) if n_rows > 1 else n_cols, k, val.data_ptr(), idx.data_ptr(),
+                                             C.c_void_p(stream.cuda_stream)))
+    v, i = val.cpu().numpy().astype(np.int64), idx.cpu().numpy().astype(np.int64)
+    order = np.lexsort((i, v), axis=1)
+    return np.take_along_axis(v, order, axis=1), np.take_along_axis(i, order, axis=1)

@@ -170,6 +170,12 @@ int dctfp_l1_matrix(dctfp_ctx* ctx, const int8_t* a, int64_t na, int64_t lda, co
 int dctfp_block_min(dctfp_ctx* ctx, const int32_t* dist, int64_t ldo, const int64_t* idx_a, int64_t npa,
                     const int64_t* idx_b, int64_t npb, int32_t* out_min, int32_t* out_last, void* stream);
 
+/* The k nearest database fingerprints of every query fingerprint: the k smallest entries of each row of an
+ * int32 distance matrix (dctfp_l1_matrix), ties to the lower column as a flat index scan returns them
+ * (index.search at src/query_db.py:87).  out_val / out_idx: device int32 (n_rows, k), unordered within a row. */
+int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k,
+                     int32_t* out_val, int32_t* out_idx, void* stream);
+
 /* Tuning / instrumentation knobs (no reference counterpart).
  *   "stage_b"      0 = plain VALU kernel, 1 = MFMA f64 kernel (default)
  *   "a_waves"      waves per workgroup of the stage-A kernel: 0 = by average rows per job (default), 2, 4, 8, 16

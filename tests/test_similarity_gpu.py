@@ -71,3 +71,15 @@ def test_query_search_matches_example_golden(tmp_path):
     out = str(tmp_path / 'search.txt')
     query_db.main(['--query', str(tmp_path / 'ex.db'), '--db', str(tmp_path / 'ex.db'), '--out', out, '--khits', '50'])
     assert open(out).read() == open(os.path.join(FIX, 'example-search.txt')).read()
+
+
+def test_row_select_matches_stable_argsort():
+    import torch
+    from dctdomain_amd.similarity import row_select
+    rng = np.random.default_rng(4)
+    for n_rows, n_cols, k, hi in ((3, 43, 43, 5000), (7, 1000, 50, 40), (1, 5, 1, 3), (5, 70000, 100, 20000), (4, 300, 300, 2)):
+        d = rng.integers(0, hi, size=(n_rows, n_cols)).astype(np.int32)
+        v, i = row_select(torch.from_numpy(d).cuda(), k)
+        order = np.argsort(d, axis=1, kind='stable')[:, :k]
+        np.testing.assert_array_equal(i, order)
+        np.testing.assert_array_equal(v, np.take_along_axis(d, order, axis=1))
