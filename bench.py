@@ -166,6 +166,7 @@ def main():
     ms_k, n_k = ctx.profile()                       # hipEvent time of stage A / stage B on the launch stream
     ctx.set_option('profile', 0)
     elapsed = ddist.max_over_ranks(elapsed, device if args.backend == 'nccl' else None)
+    fp_all_ranks = ddist.sum_over_ranks(n_fp, device if args.backend == 'nccl' else None)   # ragged workloads differ per rank
 
     # ---- parity sample against the oracle (checker only; outside the timed region) ----
     parity = None
@@ -188,7 +189,7 @@ def main():
         parity = {'checked': checked, 'mismatching_fingerprints': bad}
 
     if rank == 0:
-        total_fp = n_fp * world * args.steps
+        total_fp = fp_all_ranks * args.steps
         value = total_fp / elapsed
         # algorithmic bytes: every embedding row read once per layer + the int8 output;
         # 5,120,480 B per fingerprint at C2

@@ -73,3 +73,11 @@ def gather_to_root(obj, root: int = 0):
     out = [None] * world if dist.get_rank() == root else None
     dist.gather_object(obj, out, dst=root)
     return out
+
+
+def sum_over_ranks(value: float, device: torch.device = None) -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

@@ -28,6 +28,7 @@ def _worker(rank, world, port, lengths, ret):
     fps = np.stack([np.full(480, i % 128, np.int8) for i in mine]) if mine else np.zeros((0, 480), np.int8)
     dd.barrier()
     t = dd.max_over_ranks(1.0 + rank)
+    assert dd.sum_over_ranks(10 + rank) == 21.0
     gathered = dd.gather_to_root((mine, fps))
     if rank == 0:
         ret['t'] = t
