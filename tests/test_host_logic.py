@@ -94,3 +94,23 @@ def test_piece_table_layout():
     assert p['seq'].tolist() == [0, 0, 0, 1]
     w = PieceTable.whole_sequences([5, 7])
     assert w.pieces['n_rows'].tolist() == [5, 7] and w.keys == ['1-5', '1-7']
+
+
+def test_fingerprint_is_picklable_and_keeps_the_reference_fields():
+    """make_db passes Fingerprint objects through multiprocessing.Pool.starmap (src/make_db.py:48-49)."""
+    import pickle
+    import dataclasses
+    import dctdomain_amd as dd
+    x = np.arange(12, dtype=np.float32).reshape(4, 3)
+    fp = dd.Fingerprint(pid='P1', seq='ACDE', embed={15: x, 21: x + 1}, contacts=np.eye(4, dtype=np.float32), domains=['1-4'])
+    assert [f.name for f in dataclasses.fields(fp)] == ['pid', 'seq', 'embed', 'contacts', 'domains', 'quants']
+    fp.quants['1-4'] = np.arange(480)
+    back = pickle.loads(pickle.dumps(fp))
+    assert back.pid == 'P1' and back.domains == ['1-4'] and list(back.embed) == [15, 21]
+    np.testing.assert_array_equal(back.embed[21], x + 1)
+    np.testing.assert_array_equal(back.quants['1-4'], np.arange(480))
+    empty = dd.Fingerprint()
+    assert empty.pid == '' and empty.embed == {} and empty.domains == [] and empty.quants == {}
+    assert isinstance(empty.contacts, np.ndarray)
+    for name in ('writece', 'reccut', 'scale', 'idct_quant', 'get_doms', 'quantize'):
+        assert callable(getattr(fp, name))
