@@ -348,10 +348,10 @@ void launch_b_mfma(int nt, bool packed, unsigned grid, hipStream_t s, const char
 #define DCTFP_B_CASE(NT)                                                                                             \
     case NT:                                                                                                         \
         if (packed)                                                                                                  \
-            hipLaunchKernelGGL((stage_b_mfma_kernel<NT, true>), dim3(grid), dim3(256), 0, s, yp, job_bytes, rows, ldy, \
+            hipLaunchKernelGGL((stage_b_mfma_kernel<NT, true>), dim3(grid), dim3(DCTFP_B_WG_WAVES * 64), 0, s, yp, job_bytes, rows, ldy, \
                                st, jobs, n, m, out);                                                                 \
         else                                                                                                         \
-            hipLaunchKernelGGL((stage_b_mfma_kernel<NT, false>), dim3(grid), dim3(256), 0, s, yp, job_bytes, rows,   \
+            hipLaunchKernelGGL((stage_b_mfma_kernel<NT, false>), dim3(grid), dim3(DCTFP_B_WG_WAVES * 64), 0, s, yp, job_bytes, rows,   \
                                ldy, st, jobs, n, m, out);                                                            \
         break;
     switch (nt) {
@@ -364,10 +364,10 @@ void launch_b_mfma(int nt, bool packed, unsigned grid, hipStream_t s, const char
         DCTFP_B_CASE(7)
         default:
             if (packed)
-                hipLaunchKernelGGL((stage_b_mfma_kernel<8, true>), dim3(grid), dim3(256), 0, s, yp, job_bytes, rows, ldy,
+                hipLaunchKernelGGL((stage_b_mfma_kernel<8, true>), dim3(grid), dim3(DCTFP_B_WG_WAVES * 64), 0, s, yp, job_bytes, rows, ldy,
                                    st, jobs, n, m, out);
             else
-                hipLaunchKernelGGL((stage_b_mfma_kernel<8, false>), dim3(grid), dim3(256), 0, s, yp, job_bytes, rows, ldy,
+                hipLaunchKernelGGL((stage_b_mfma_kernel<8, false>), dim3(grid), dim3(DCTFP_B_WG_WAVES * 64), 0, s, yp, job_bytes, rows, ldy,
                                    st, jobs, n, m, out);
             break;
     }
@@ -884,7 +884,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             if (rc) return rc;
             if (ctx->opt_stage_b == 1) {
                 const int64_t rows = jn * n;
-                launch_b_mfma(st->cp / 16, packed, (unsigned)((rows + 63) / 64), sb, yprime, (int64_t)job_bytes, rows, ldy,
+                launch_b_mfma(st->cp / 16, packed, (unsigned)((rows + DCTFP_B_WG_WAVES * 16 - 1) / (DCTFP_B_WG_WAVES * 16)), sb, yprime, (int64_t)job_bytes, rows, ldy,
                               st->dev, djb + j0, n, m, out);
             } else {
                 hipLaunchKernelGGL(stage_b_valu_kernel, dim3((unsigned)jn), dim3(256), 0, sb, (const double*)yprime, ldy, g.n_cols,

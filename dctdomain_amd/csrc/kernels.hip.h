@@ -355,11 +355,14 @@ __device__ inline int8_t quant127(double num, double den, bool bad) {
 //   f64 MFMA layouts (cdna_hip_programming.md section 3): A[i = l&15][k = l>>4],
 //   B[k = l>>4][j = l&15], C/D reg i: row = (l>>4) + 4 i, col = l & 15.
 // ---------------------------------------------------------------------------
+#ifndef DCTFP_B_WG_WAVES
+#define DCTFP_B_WG_WAVES 4  // waves (16-row tiles) per stage-B workgroup (A/B: tools/ab_build_run.sh)
+#endif
 #ifndef DCTFP_B_MIN_WAVES
 #define DCTFP_B_MIN_WAVES 2  // register budget of stage B as waves per SIMD (A/B: tools/ab_build_run.sh)
 #endif
 template <int NT, bool PACKED>
-__global__ __launch_bounds__(256, DCTFP_B_MIN_WAVES) void stage_b_mfma_kernel(const char* __restrict__ ypb, int64_t job_bytes,
+__global__ __launch_bounds__(DCTFP_B_WG_WAVES * 64, DCTFP_B_MIN_WAVES) void stage_b_mfma_kernel(const char* __restrict__ ypb, int64_t job_bytes,
                                                             int64_t n_rows_total, int ldy, const double* __restrict__ st,
                                                             const JobB* __restrict__ jobs, int n, int m,
                                                             int8_t* __restrict__ out) {
@@ -375,7 +378,8 @@ __global__ __launch_bounds__(256, DCTFP_B_MIN_WAVES) void stage_b_mfma_kernel(co
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane >> 4, r16 = lane & 15;
-    const int64_t row0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    constexpr int BT = DCTFP_B_WG_WAVES * 64;  // threads per workgroup
+    const int64_t row0 = (int64_t)blockIdx.x * (DCTFP_B_WG_WAVES * 16) + wave * 16;
     int64_t arow = row0 + r16;
     if (arow >= n_rows_total) arow = n_rows_total - 1;
     // A operand source: row (job, j) of Y'.  Plain: float64 row.  PACKED (n = 3): the job's t row + state bytes.
@@ -412,12 +416,12 @@ __global__ __launch_bounds__(256, DCTFP_B_MIN_WAVES) void stage_b_mfma_kernel(co
 
     // Software pipeline: the St chunk and the A fragments of step kb+1 are fetched into registers
     // while the MFMAs of step kb run, so no global-memory latency sits between two barriers.
-    constexpr int PER = (KB * CP / 2 + 255) / 256;  // v2d pieces of an St chunk per thread
+    constexpr int PER = (KB * CP / 2 + BT - 1) / BT;  // v2d pieces of an St chunk per thread
     v2d nxt[PER];
     auto fetch_st = [&](int kb) {
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            const int i = threadIdx.x + e * 256;
+            const int i = threadIdx.x + e * BT;
             if (i < KB * CP / 2) {
                 const int kk = i / (CP / 2), cc = (i % (CP / 2)) * 2;
                 nxt[e] = *reinterpret_cast<const v2d*>(st + (size_t)(kb + kk) * CP + cc);
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(256, DCTFP_B_MIN_WAVES) void stage_b_mfma_kernel(co
         __syncthreads();  // the MFMAs of the previous step have read bs
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            const int i = threadIdx.x + e * 256;
+            const int i = threadIdx.x + e * BT;
             if (i < KB * CP / 2) {
                 const int kk = i / (CP / 2), cc = (i % (CP / 2)) * 2;
                 bs[kk][cc] = nxt[e][0];
