@@ -146,6 +146,17 @@ struct dctfp_ctx {
     int device = 0;
     int64_t opt_overlap = 4;
     hipStream_t side = nullptr;
+    hipStream_t copy = nullptr;                 // table upload + cosine tables, ahead of the caller's stream
+    hipEvent_t ev_tab_free[2] = {}, ev_tab_ready = nullptr;
+    bool tab_busy[2] = {false, false};
+    int ensure_copy() {
+        if (copy) return DCTFP_OK;
+        if (hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) { copy = nullptr; g_err = "hipStreamCreate(copy) failed"; return DCTFP_ERR_HIP; }
+        if (hipEventCreateWithFlags(&ev_tab_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_tab_free[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_tab_free[1], hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; return DCTFP_ERR_HIP; }
+        return DCTFP_OK;
+    }
     hipEvent_t ev_a[kMaxSlots] = {}, ev_b[kMaxSlots] = {};
     int ensure_side() {
         if (side) return DCTFP_OK;
@@ -178,6 +189,16 @@ struct dctfp_ctx {
 namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Records that `stream` has (enqueued) the last reader of table buffer `buf`: a later dctfp_quantize uploads into it
+// from the copy stream only after this point.
+int mark_table_used(dctfp_ctx* ctx, int buf, hipStream_t stream) {
+    int rc = ctx->ensure_copy();
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_tab_free[buf], stream));
+    ctx->tab_busy[buf] = true;
+    return DCTFP_OK;
+}
 
 inline size_t dtype_size(int dtype) { return dtype == DCTFP_F64 ? 8 : (dtype == DCTFP_F32 ? 4 : 2); }
 
@@ -438,6 +459,12 @@ int dctfp_destroy(dctfp_ctx* ctx) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
+    if (ctx->copy) {
+        (void)hipStreamDestroy(ctx->copy);
+        (void)hipEventDestroy(ctx->ev_tab_ready);
+        (void)hipEventDestroy(ctx->ev_tab_free[0]);
+        (void)hipEventDestroy(ctx->ev_tab_free[1]);
+    }
     if (ctx->side) {
         (void)hipStreamDestroy(ctx->side);
         for (int i = 0; i < kMaxSlots; ++i) {
@@ -651,8 +678,9 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const size_t off_piece = align_up(off_joba + (size_t)n_jobs * sizeof(JobA), 16);
         const size_t off_walk = align_up(off_piece + (size_t)ng * n_pieces * sizeof(PieceA), 16);
         const size_t off_lens = align_up(off_walk + (size_t)n_jobs * sizeof(Walk), 16);
-        Staging& stg = ctx->staging[ctx->flip];
-        DevBuf& tab = ctx->tables[ctx->flip];
+        const int buf = ctx->flip;
+        Staging& stg = ctx->staging[buf];
+        DevBuf& tab = ctx->tables[buf];
         ctx->flip ^= 1;
         // unique lengths (at most n_domains)
         const size_t max_bytes = align_up(off_lens + 2 * (size_t)n_domains * sizeof(uint32_t), 16);
@@ -794,8 +822,13 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const size_t off_basis = align_up(tab_bytes, 256);
         rc = tab.ensure(off_basis + (size_t)basis_doubles * sizeof(double));
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(tab.p, stg.p, tab_bytes, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipEventRecord(stg.ev, stream));
+        // The tables go up on the context's copy stream, so the upload of this call overlaps the kernels of
+        // the previous one; the copy waits until the last user of this table buffer (two calls ago) is done.
+        rc = ctx->ensure_copy();
+        if (rc) return rc;
+        if (ctx->tab_busy[buf]) HIP_TRY(hipStreamWaitEvent(ctx->copy, ctx->ev_tab_free[buf], 0));
+        HIP_TRY(hipMemcpyAsync(tab.p, stg.p, tab_bytes, hipMemcpyHostToDevice, ctx->copy));
+        HIP_TRY(hipEventRecord(stg.ev, ctx->copy));
         stg.pending = true;
         char* dt = (char*)tab.p;
         const JobB* djb = (const JobB*)(dt + off_jobb);
@@ -807,10 +840,14 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         double* dbasis = (double*)(dt + off_basis);
 
         if (trivial) {
+            HIP_TRY(hipEventRecord(ctx->ev_tab_ready, ctx->copy));
+            HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_ready, 0));
             const int64_t total = n_jobs * n * m;
             const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
             hipLaunchKernelGGL(fill_zero_kernel, dim3(grid), dim3(256), 0, stream, djb, n_jobs, n * m, out);
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(ctx->ev_tab_free[buf], stream));
+            ctx->tab_busy[buf] = true;
             l0 = l1;
             continue;
         }
@@ -824,9 +861,11 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             uint32_t max_len = 0;
             for (size_t i = 0; i < nu; ++i) max_len = std::max(max_len, ulen[i]);
             const unsigned gx = (unsigned)std::min<uint64_t>(((uint64_t)max_len * nk + 255) / 256, 1024);
-            hipLaunchKernelGGL(basis_kernel, dim3(gx, (unsigned)nu), dim3(256), 0, stream, dlens, doffs, nk, dbasis);
+            hipLaunchKernelGGL(basis_kernel, dim3(gx, (unsigned)nu), dim3(256), 0, ctx->copy, dlens, doffs, nk, dbasis);
             HIP_TRY(hipGetLastError());
         }
+        HIP_TRY(hipEventRecord(ctx->ev_tab_ready, ctx->copy));
+        HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_ready, 0));
 
         // Stage A of chunk c runs on the caller's stream, stage B of it on the context's side
         // stream, so the MFMA-bound stage B of one chunk overlaps the HBM-bound stage A of the next.
@@ -900,6 +939,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             const int64_t used = std::min<int64_t>(c, slots);
             for (int64_t k = 0; k < used; ++k) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_b[k], 0));
         }
+        HIP_TRY(hipEventRecord(ctx->ev_tab_free[buf], stream));  // this table buffer may be overwritten after this point
+        ctx->tab_busy[buf] = true;
         l0 = l1;
     }
     return DCTFP_OK;
@@ -947,8 +988,9 @@ int dctfp_gather_rows(dctfp_ctx* ctx, const void* embed, int32_t dtype, int64_t 
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t esz = dtype == DCTFP_F32 ? 4 : 8;
-    Staging& stg = ctx->staging[ctx->flip];
-    DevBuf& tab = ctx->tables[ctx->flip];
+    const int buf = ctx->flip;
+    Staging& stg = ctx->staging[buf];
+    DevBuf& tab = ctx->tables[buf];
     ctx->flip ^= 1;
     int rc = stg.ensure((size_t)n_pieces * sizeof(PieceA));
     if (rc) return rc;
@@ -977,7 +1019,7 @@ int dctfp_gather_rows(dctfp_ctx* ctx, const void* embed, int32_t dtype, int64_t 
     else
         hipLaunchKernelGGL((gather_rows_kernel<double>), dim3(gx, (unsigned)n_pieces), dim3(256), 0, stream, (const PieceA*)tab.p, (int)n_pieces, n_cols, ld, out);
     HIP_TRY(hipGetLastError());
-    return DCTFP_OK;
+    return mark_table_used(ctx, buf, stream);
 }
 
 
@@ -990,8 +1032,9 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
     if (n_prot == 0) return DCTFP_OK;
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_TRY(hipSetDevice(ctx->device));
-    Staging& stg = ctx->staging[ctx->flip];
-    DevBuf& tab = ctx->tables[ctx->flip];
+    const int buf = ctx->flip;
+    Staging& stg = ctx->staging[buf];
+    DevBuf& tab = ctx->tables[buf];
     ctx->flip ^= 1;
     int rc = stg.ensure((size_t)n_prot * sizeof(TopkJob));
     if (rc) return rc;
@@ -1017,7 +1060,7 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
     hipLaunchKernelGGL(contact_topk_kernel, dim3((unsigned)n_prot), dim3(1024), 0, stream, (const TopkJob*)tab.p, out_i,
                        out_j, out_v, out_n);
     HIP_TRY(hipGetLastError());
-    return DCTFP_OK;
+    return mark_table_used(ctx, buf, stream);
 }
 
 int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, int32_t n_cols, int32_t square,
@@ -1039,8 +1082,9 @@ int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, i
         if (j.level == 0 && j.n_avg != 0) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: window %lld: level 0 cannot average", (long long)i);
         max_level = std::max(max_level, j.level);
     }
-    Staging& stg = ctx->staging[ctx->flip];
-    DevBuf& tab = ctx->tables[ctx->flip];
+    const int buf = ctx->flip;
+    Staging& stg = ctx->staging[buf];
+    DevBuf& tab = ctx->tables[buf];
     ctx->flip ^= 1;
     int rc = stg.ensure((size_t)n_jobs * sizeof(StitchJob));
     if (rc) return rc;
@@ -1081,7 +1125,7 @@ int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, i
             done += ny;
         }
     }
-    return DCTFP_OK;
+    return mark_table_used(ctx, buf, stream);
 }
 
 int dctfp_l1_matrix(dctfp_ctx* ctx, const int8_t* a, int64_t na, int64_t lda, const int8_t* b, int64_t nb, int64_t ldb,
