@@ -9,7 +9,20 @@ for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden
         sys.path.insert(0, p)
 
 
+def _ensure_native_built():
+    """The suites import dctdomain_amd, which refuses to load without its HIP library.  Normally
+    __graft_entry__.build() has produced it; build it here when a fresh checkout runs pytest first
+    (hipcc cross-compiles without a GPU).  The CPU checkers of oracle/ are built the same way."""
+    import subprocess
+    import build_ext
+    if not (os.path.exists(build_ext.LIB_PATH) and os.path.exists(build_ext.RECCUT_LIB_PATH)):
+        build_ext.build_all()
+    if not os.path.exists(os.path.join(ROOT, 'oracle', '_build', 'liboracle.so')):
+        subprocess.run(['make', '-C', os.path.join(ROOT, 'oracle'), 'all'], check=True)
+
+
 def pytest_configure(config):
+    _ensure_native_built()
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
