@@ -219,7 +219,7 @@ def build_parser() -> argparse.ArgumentParser:
     # additions of this build
     parser.add_argument('--model', choices=['esm', 'synthetic'], default='esm',
                         help='language model: fair-esm ESM-2 (as the reference) or the synthetic stand-in')
-    parser.add_argument('--flush', type=int, default=256, help='proteins per batched fingerprint call')
+    parser.add_argument('--flush', type=int, default=1024, help='proteins per batched fingerprint call')
     return parser
 
 
