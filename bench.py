@@ -31,7 +31,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--n-seq', type=int, default=10000, help='sequences per GPU (weak scaling)')
     ap.add_argument('--seq-len', type=int, default=500)
-    ap.add_argument('--dim', type=int, default=1280)
+    ap.add_argument('--dim', type=int, default=None, help='embedding width (default: 1280 for c2/c3, 2560 for c4, 640 for c5)')
     ap.add_argument('--layers', type=int, default=2)
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the CPU baseline leg')
     ap.add_argument('--cpu-procs', type=int, default=0,
@@ -71,10 +71,10 @@ def make_workload(args, rank, np):
     """(lengths, domain strings per sequence or None for whole-sequence domains, D)."""
     n_seq = args.n_seq
     if args.workload == 'c2':
-        return np.full(n_seq, args.seq_len, dtype=np.int64), None, args.dim
+        return np.full(n_seq, args.seq_len, dtype=np.int64), None, args.dim or 1280
     rng = np.random.default_rng(2024 + rank)
     if args.workload == 'c3':       # BASELINE config 3: ragged lengths, whole-sequence domains
-        return rng.integers(50, 2001, size=n_seq).astype(np.int64), None, args.dim
+        return rng.integers(50, 2001, size=n_seq).astype(np.int64), None, args.dim or 1280
     if args.workload == 'c5':       # BASELINE config 5 flavour: what a database build feeds the path
         lengths = np.clip(rng.gamma(2.2, 170.0, size=n_seq).astype(np.int64), 81, 1330)
         dim, target = 640, 110      # esm2_t30 width; RecCut domains are ~100 residues
@@ -91,7 +91,7 @@ def make_workload(args, rank, np):
         cuts = np.sort(rng.choice(np.arange(1, int(L) // 25), size=k - 1, replace=False)) * 25
         edges = [0] + [int(c) for c in cuts] + [int(L)]
         doms.append([f'{a + 1}-{b}' for a, b in zip(edges[:-1], edges[1:])] + [f'1-{L}'])
-    return lengths, doms, dim
+    return lengths, doms, args.dim or dim
 
 
 def main():
@@ -109,7 +109,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import cpu_baseline as cb
         procs = args.cpu_procs if args.cpu_procs > 0 else min(cb.usable_cores(), 16)
-        cpu_baseline = cb.run(args.seq_len, args.dim, args.layers, tuple([3, 80] * args.layers), args.cpu_seconds,
+        cpu_baseline = cb.run(args.seq_len, args.dim or 1280, args.layers, tuple([3, 80] * args.layers), args.cpu_seconds,
                               procs=procs)
 
     import numpy as np
