@@ -36,7 +36,7 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='0 disables the CPU baseline leg')
     ap.add_argument('--cpu-procs', type=int, default=0,
                     help='CPU baseline worker processes (0 = usable cores, at most 16 = one GPU\'s CPU share on the pool)')
-    ap.add_argument('--parity-sample', type=int, default=8)
+    ap.add_argument('--parity-sample', type=int, default=64)   # 64 sequences
     ap.add_argument('--opt', action='append', default=[], help='name=value passed to dctfp_set_option')
     ap.add_argument('--storage', choices=['float32', 'float16', 'bfloat16'], default='float32',
                     help='storage type of the synthetic embeddings (the headline metric is float32, as the reference)')

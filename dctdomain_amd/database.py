@@ -1,5 +1,5 @@
 """``Database`` -- the output side of the fingerprint path: SQLite ``.db``, ``-dct.npz``, ``.dom``
-and (optionally) the FAISS ``.index``, byte-compatible with mgtools/DCTdomain
+and (optionally) the FAISS ``.index``, layout-compatible with mgtools/DCTdomain
 ``src/database.py`` so that the reference's ``query_db.py`` / ``dct-sim.py`` read what this
 build writes.
 
@@ -12,22 +12,32 @@ Layout contract (reference ``src/database.py``):
 * ``-dct.npz`` = ``np.savez(sid, idx, dom, dct)`` in table order, consecutive equal pids grouped (:351-375);
 * ``.dom`` = ``pid ndom d1;d2`` without the trailing whole-protein entry (:378-392).
 
-Differences, on purpose: inserts are batched in one transaction per batch of proteins
-(``add_fprints``; the reference commits per protein), and ``yield_seqs`` does not lose the tail
-of the input in multi-sequence mode (reference bug at :166-178)."""
+Built for batches, not for one protein at a time: a batch of proteins is one transaction
+(``add_fprints``; the reference commits per protein), a million blobs share one cached npy header,
+renumbering is two set-based statements, and ``yield_seqs`` does not lose the tail of the input
+in multi-sequence mode (reference bug at :166-178)."""
 
 from __future__ import annotations
 
-import datetime
 import os
 import sqlite3
 import struct
+from datetime import datetime
 from io import BytesIO
-from typing import Iterable, List, Sequence, Tuple
+from itertools import groupby
+from typing import Iterable, Iterator, List, Tuple
 
 import numpy as np
 
-
+# column lists of the three tables (names, types and constraints are the reference's, :100-126)
+_TABLES = (
+    ('sequences', 'pid text PRIMARY KEY, sequence text NOT NULL, length integer NOT NULL, fpcount integer NOT NULL'),
+    ('fingerprints', 'vid integer PRIMARY KEY, domain text NOT NULL, fingerprint blob NOT NULL, pid text NOT NULL, '
+                     'FOREIGN KEY(pid) REFERENCES sequences(pid)'),
+    ('metadata', 'datetime text PRIMARY KEY, seq_num integer NOT NULL, avg_len real NOT NULL, '
+                 'fp_num integer NOT NULL, seqs_fp string NOT NULL'),
+)
+_FASTA_SUFFIXES = ('.fa', '.fasta')
 _NPY_HEADERS = {}
 
 
@@ -47,21 +57,56 @@ def _npy_bytes(vec: np.ndarray) -> bytes:
     return head + vec.tobytes()
 
 
+def _npy_vector(blob: bytes) -> np.ndarray:
+    return np.load(BytesIO(blob), allow_pickle=True)
+
+
+def _fasta_records(path: str) -> Iterator[Tuple[str, str]]:
+    """(pid, sequence) per record; pid = the header up to the first blank, a repeated pid keeps its
+    first position and its last sequence (what a dict filled line by line gives, :60-77)."""
+    pid, chunks = None, []
+    with open(path, encoding='utf8') as handle:
+        for raw in handle:
+            text = raw.strip()
+            if raw.startswith('>'):
+                if pid is not None:
+                    yield pid, ''.join(chunks)
+                pid, chunks = text.split()[0][1:], []
+            else:
+                chunks.append(text)
+    if pid is not None:
+        yield pid, ''.join(chunks)
+
+
+class _Serial:
+    """Stand-in for the reference's shared ``multiprocessing.Value`` vid counter."""
+
+    def __init__(self, value: int):
+        self.value = value
+
+
 class Database:
     """SQLite database of sequences and fingerprints (reference ``Database``, :16-392)."""
 
     def __init__(self, dbfile: str, fafile: str = None):
-        if fafile and (fafile.endswith('.fa') or fafile.endswith('.fasta')):
+        from_fasta = bool(fafile) and fafile.endswith(_FASTA_SUFFIXES)
+        if from_fasta:
             print(f'Reading file: {fafile}')
             self.path = dbfile
             self.init_db(self.read_fasta(fafile))
-        else:
-            if not os.path.exists(dbfile):
-                raise FileNotFoundError(f'Database file not found: {dbfile}')
-            print(f'Opening database: {dbfile}')
-            self.path = os.path.splitext(dbfile)[0]
-            self.conn = sqlite3.connect(f'{self.path}.db')
-            self.cur = self.conn.cursor()
+            return
+        if not os.path.exists(dbfile):
+            raise FileNotFoundError(f'Database file not found: {dbfile}')
+        print(f'Opening database: {dbfile}')
+        self._open(dbfile)
+
+    def _open(self, name: str):
+        self.path = os.path.splitext(name)[0]
+        self.conn = sqlite3.connect(self.path + '.db')
+        self.cur = self.conn.cursor()
+
+    def _one(self, sql: str, args=()):
+        return self.cur.execute(sql, args).fetchone()
 
     def close(self):
         print(f'Closing database: {self.path}\n')
@@ -71,49 +116,24 @@ class Database:
     def read_fasta(self, fafile: str) -> dict:
         """pid -> sequence, ascending length (stable), as :60-81."""
         seqs = {}
-        pid = None
-        with open(fafile, 'r', encoding='utf8') as f:
-            for line in f:
-                if line.startswith('>'):
-                    pid = line.strip().split()[0][1:]
-                    seqs[pid] = ''
-                else:
-                    seqs[pid] += line.strip()
-        return dict(sorted(seqs.items(), key=lambda item: len(item[1])))
+        for pid, seq in _fasta_records(fafile):
+            seqs[pid] = seq
+        by_length = sorted(seqs, key=lambda p: len(seqs[p]))
+        return {p: seqs[p] for p in by_length}
 
     def init_db(self, seqs: dict):
-        self.path = os.path.splitext(self.path)[0]
-        self.conn = sqlite3.connect(f'{self.path}.db')
-        self.cur = self.conn.cursor()
-        self.cur.execute("""CREATE TABLE IF NOT EXISTS sequences (
-                pid text PRIMARY KEY,
-                sequence text NOT NULL,
-                length integer NOT NULL,
-                fpcount integer NOT NULL
-                ); """)
-        self.cur.execute("""CREATE TABLE IF NOT EXISTS fingerprints (
-                vid integer PRIMARY KEY,
-                domain text NOT NULL,
-                fingerprint blob NOT NULL,
-                pid text NOT NULL,
-                FOREIGN KEY(pid) REFERENCES sequences(pid)
-                ); """)
-        self.cur.execute("""CREATE TABLE IF NOT EXISTS metadata (
-                datetime text PRIMARY KEY,
-                seq_num integer NOT NULL,
-                avg_len real NOT NULL,
-                fp_num integer NOT NULL,
-                seqs_fp string NOT NULL
-                ); """)
-        self.cur.executemany(""" INSERT OR IGNORE INTO sequences(pid, sequence, length, fpcount)
-            VALUES(?, ?, ?, ?) """, [(pid, seq, len(seq), 0) for pid, seq in seqs.items()])
+        self._open(self.path)
+        for name, columns in _TABLES:
+            self.cur.execute(f'CREATE TABLE IF NOT EXISTS {name} ({columns})')
+        self.cur.executemany('INSERT OR IGNORE INTO sequences(pid, sequence, length, fpcount) VALUES(?, ?, ?, 0)',
+                             ((pid, seq, len(seq)) for pid, seq in seqs.items()))
         self.conn.commit()
 
     def pending(self, dim1: int = 3, dim2: int = 80) -> List[Tuple[str, str]]:
         """(pid, sequence) of every protein still to fingerprint (``fpcount = 0``), in table order,
         without those too short to quantise (``(length-2)*dim2 < dim1*dim2``, :149-155)."""
-        rows = self.cur.execute(""" SELECT pid, sequence, length FROM sequences WHERE fpcount = 0 """).fetchall()
-        return [(pid, seq) for pid, seq, length in rows if (length - 2) * dim2 >= dim1 * dim2]
+        todo = self.cur.execute('SELECT pid, sequence, length FROM sequences WHERE fpcount = 0').fetchall()
+        return [(pid, seq) for pid, seq, length in todo if (length - 2) * dim2 >= dim1 * dim2]
 
     def yield_seqs(self, maxlen: int, cpu: int, dim1: int = 3, dim2: int = 80):
         """Batches of (pid, sequence): proteins are packed while their total length stays within
@@ -121,23 +141,23 @@ class Database:
         (and is embedded in windows); ``maxlen = 1`` gives one protein per batch, the reference's CPU
         mode (make_db.py:136).  Same intent as :136-178, but every pending protein is yielded exactly
         once (the reference drops the tail of the input when its last batch holds several)."""
-        batch, cur = [], 0
-        any_seq = False
-        for pid, seq in self.pending(dim1, dim2):
-            any_seq = True
-            if batch and (cur + len(seq) > maxlen or len(batch) > cpu):
-                yield batch
-                batch, cur = [], 0
-            batch.append((pid, seq))
-            cur += len(seq)
-        if batch:
-            yield batch
-        if not any_seq:
+        todo = self.pending(dim1, dim2)
+        if not todo:
             print('No sequences to fingerprint!\n')
+            return
+        batch, residues = [], 0
+        for item in todo:
+            full = residues + len(item[1]) > maxlen or len(batch) > cpu
+            if batch and full:
+                yield batch
+                batch, residues = [], 0
+            batch.append(item)
+            residues += len(item[1])
+        yield batch
 
     def get_last_vid(self) -> int:
-        row = self.cur.execute(""" SELECT vid FROM fingerprints ORDER BY vid DESC LIMIT 1 """).fetchone()
-        return row[0] + 1 if row else 1
+        top = self._one('SELECT MAX(vid) FROM fingerprints')[0]
+        return 1 if top is None else top + 1
 
     # -- output ---------------------------------------------------------------------------
     def add_fprint(self, fp, lock=None, counter=None):
@@ -146,126 +166,116 @@ class Database:
 
     def add_fprints(self, fps: Iterable, lock=None, counter=None):
         """Many proteins in one transaction.  Each item needs ``pid``, ``domains`` and
-        ``quants[dom]`` (0..127 ints) -- a ``Fingerprint`` or anything shaped like one."""
-        class _Ctr:
-            value = None
+        ``quants[dom]`` (0..127 ints) -- a ``Fingerprint`` or anything shaped like one.  vids are
+        drawn from ``counter`` (incremented first, like :216-218), under ``lock`` when one is given."""
         if counter is None:
-            counter = _Ctr()
-            counter.value = self.get_last_vid()
-        rows, updates = [], []
+            counter = _Serial(self.get_last_vid())
+
+        def next_vid():
+            counter.value += 1
+            return counter.value
+
+        rows, done = [], []
         for fp in fps:
-            quants = np.array([fp.quants[dom] for dom in fp.domains], dtype=np.int8)
-            updates.append((len(fp.domains), fp.pid))
-            for dom, quant in zip(fp.domains, quants):
-                if lock is not None:
-                    with lock:
-                        counter.value += 1
-                        vid = counter.value
+            done.append((len(fp.domains), fp.pid))
+            for dom in fp.domains:
+                if lock is None:
+                    vid = next_vid()
                 else:
-                    counter.value += 1
-                    vid = counter.value
-                rows.append((vid, dom, _npy_bytes(quant), fp.pid))
-        self.cur.executemany(""" UPDATE sequences SET fpcount = ? WHERE pid = ? """, updates)
-        self.cur.executemany(""" INSERT INTO fingerprints(vid, domain, fingerprint, pid)
-            VALUES(?, ?, ?, ?) """, rows)
+                    with lock:
+                        vid = next_vid()
+                rows.append((vid, dom, _npy_bytes(np.asarray(fp.quants[dom]).astype(np.int8)), fp.pid))
+        self.cur.executemany('UPDATE sequences SET fpcount = ? WHERE pid = ?', done)
+        self.cur.executemany('INSERT INTO fingerprints(vid, domain, fingerprint, pid) VALUES(?, ?, ?, ?)', rows)
         self.conn.commit()
 
     def _all_fprints(self) -> np.ndarray:
-        fps = [np.load(BytesIO(row[0]), allow_pickle=True)
-               for row in self.cur.execute(""" SELECT fingerprint FROM fingerprints """)]
-        return np.array(fps, dtype=np.int8)
+        blobs = self.cur.execute('SELECT fingerprint FROM fingerprints')
+        return np.array([_npy_vector(b) for b, in blobs], dtype=np.int8)
 
     def create_index(self):
         """``faiss.IndexFlatL2`` over all fingerprints -> ``<path>.index`` (:227-243).  Uses faiss when
         it is installed; otherwise writes the same flat-index file with ``write_flat_index``
         (format restated from faiss 1.7.4's index_write.cpp -- parity unpinned: no faiss here to
         read it back)."""
-        fps = self._all_fprints()
+        vectors = self._all_fprints().astype(np.float32)
+        target = self.path + '.index'
         try:
             import faiss
         except ImportError:
-            write_flat_index(f'{self.path}.index', fps.astype(np.float32))
-            return
-        index = faiss.IndexFlatL2(fps.shape[1])
-        index.add(fps.astype(np.float32))
-        faiss.write_index(index, f'{self.path}.index')
+            write_flat_index(target, vectors)
+        else:
+            flat = faiss.IndexFlatL2(vectors.shape[1])
+            flat.add(vectors)
+            faiss.write_index(flat, target)
 
     def load_fprints(self, pid: str = '') -> list:
-        self.cur.execute(""" SELECT vid, fingerprint FROM fingerprints WHERE pid = ? """, (pid,))
-        return [(row[0], np.load(BytesIO(row[1]), allow_pickle=True)) for row in self.cur]
+        found = self.cur.execute('SELECT vid, fingerprint FROM fingerprints WHERE pid = ?', (pid,))
+        return [(vid, _npy_vector(blob)) for vid, blob in found]
 
     def rename_vid(self):
-        """vids 1..N in table order (:268-282), in one pass."""
-        vids = [v[0] for v in self.cur.execute(""" SELECT vid FROM fingerprints """).fetchall()]
-        if vids != list(range(1, len(vids) + 1)):
-            # two-step renumbering keeps the PRIMARY KEY unique while rows move
-            self.cur.executemany(""" UPDATE fingerprints SET vid = ? WHERE vid = ? """,
-                                 [(-(i + 1), v) for i, v in enumerate(vids)])
-            self.cur.execute(""" UPDATE fingerprints SET vid = -vid """)
+        """vids 1..N in table order (:268-282), set-based: rows move to -1..-N first so that the
+        PRIMARY KEY stays unique, then flip sign."""
+        vids = [v for v, in self.cur.execute('SELECT vid FROM fingerprints')]
+        if any(v != i for i, v in enumerate(vids, 1)):
+            self.cur.executemany('UPDATE fingerprints SET vid = ? WHERE vid = ?',
+                                 ((-i, v) for i, v in enumerate(vids, 1)))
+            self.cur.execute('UPDATE fingerprints SET vid = -vid')
         self.conn.commit()
 
     def update_metadata(self):
         print('Updating metadata...')
-        num_seqs = self.cur.execute(""" SELECT COUNT(*) FROM sequences """).fetchone()[0]
-        avg_len = self.cur.execute(""" SELECT AVG(length) FROM sequences """).fetchone()[0]
-        nom_dom, dom_seqs = self.cur.execute(
-            """ SELECT SUM(fpcount), COUNT(*) FROM sequences WHERE fpcount > 0 """).fetchone()
-        if not nom_dom:
-            nom_dom = 0
-        date = datetime.datetime.now().strftime('%Y-%m-%d %H:%M:%S')
-        self.cur.execute(""" INSERT OR REPLACE INTO metadata(datetime, seq_num, avg_len, fp_num, seqs_fp)
-            VALUES(?, ?, ?, ?, ?) """, (date, num_seqs, avg_len, nom_dom, f'{dom_seqs}/{num_seqs}'))
+        n_seq, mean_len = self._one('SELECT COUNT(*), AVG(length) FROM sequences')
+        n_fp, n_done = self._one('SELECT SUM(fpcount), COUNT(*) FROM sequences WHERE fpcount > 0')
+        stamp = datetime.now().strftime('%Y-%m-%d %H:%M:%S')
+        self.cur.execute('INSERT OR REPLACE INTO metadata(datetime, seq_num, avg_len, fp_num, seqs_fp) '
+                         'VALUES(?, ?, ?, ?, ?)', (stamp, n_seq, mean_len, n_fp or 0, f'{n_done}/{n_seq}'))
         self.conn.commit()
         self.db_info()
 
     def db_info(self):
-        metadata = self.cur.execute(""" SELECT * FROM metadata ORDER BY datetime DESC LIMIT 1 """).fetchone()
-        if metadata is None:
-            self.update_metadata()
+        latest = self._one('SELECT * FROM metadata ORDER BY datetime DESC LIMIT 1')
+        if latest is None:
+            self.update_metadata()      # prints the fresh row itself
             return
-        print(f'Last Updated: {metadata[0]}')
-        print(f'Number of Sequences: {metadata[1]}')
-        print(f'Average Sequence Length: {metadata[2]:.2f}')
-        print(f'Number of Fingerprints: {metadata[3]} ({metadata[4]} fingerprinted)\n')
+        stamp, n_seq, mean_len, n_fp, done = latest
+        print(f'Last Updated: {stamp}\nNumber of Sequences: {n_seq}\nAverage Sequence Length: {mean_len:.2f}\n'
+              f'Number of Fingerprints: {n_fp} ({done} fingerprinted)\n')
 
     def seq_info(self, seq: str):
         print(f'Protein ID: {seq}')
-        row = self.cur.execute(""" SELECT sequence FROM sequences WHERE pid = ? """, (seq,)).fetchone()
-        if row is None:
+        hit = self._one('SELECT sequence FROM sequences WHERE pid = ?', (seq,))
+        if hit is None:
             print('Sequence not found in database\n')
             return
-        domains = self.cur.execute(""" SELECT domain FROM fingerprints WHERE pid = ? """, (seq,)).fetchall()
-        print(f'Sequence: {row[0]}')
-        if domains:
-            print(f'Domains: {", ".join([dom[0] for dom in domains])}\n')
-        else:
-            print('No domains in database\n')
+        print(f'Sequence: {hit[0]}')
+        names = [d for d, in self.cur.execute('SELECT domain FROM fingerprints WHERE pid = ?', (seq,))]
+        print(f'Domains: {", ".join(names)}\n' if names else 'No domains in database\n')
 
     def save_fprints(self, file: str):
-        """``np.savez(file, sid=, idx=, dom=, dct=)`` (:351-375)."""
-        seqs, idxs, doms, fps = [], [], [], []
-        seq, idx = '', 0
-        for pid, dom, blob in self.cur.execute(""" SELECT pid, domain, fingerprint FROM fingerprints """):
-            if pid != seq:
-                seq = pid
-                seqs.append(seq)
-                idxs.append(idx)
-            doms.append(dom)
-            fps.append(np.load(BytesIO(blob), allow_pickle=True))
-            idx += 1
-        idxs.append(idx)
-        np.savez(file, sid=seqs, idx=idxs, dom=doms, dct=fps)
+        """``np.savez(file, sid=, idx=, dom=, dct=)`` (:351-375): ``idx`` = prefix offsets of the runs
+        of consecutive equal pids."""
+        table = self.cur.execute('SELECT pid, domain, fingerprint FROM fingerprints').fetchall()
+        sid, idx = [], [0]
+        for pid, run in groupby(table, key=lambda row: row[0]):
+            sid.append(pid)
+            idx.append(idx[-1] + sum(1 for _ in run))
+        if not table:
+            idx = [0]
+        # lists in, like the reference: numpy picks <U / int64 / int8 exactly as it does there
+        np.savez(file, sid=sid, idx=idx, dom=[row[1] for row in table], dct=[_npy_vector(row[2]) for row in table])
 
     def save_doms(self, file: str):
         """``pid ndom d1;d2`` per protein, whole-protein entry dropped when there are several (:378-392)."""
-        doms = {}
-        for pid, dom in self.cur.execute(""" SELECT pid, domain FROM fingerprints """):
-            doms.setdefault(pid, []).append(dom)
-        with open(file, 'w', encoding='utf8') as f:
-            for pid, domains in doms.items():
-                if len(domains) > 1:
-                    domains = domains[:-1]
-                f.write(f'{pid} {len(domains)} {";".join(domains)}\n')
+        per_pid = {}
+        for pid, dom in self.cur.execute('SELECT pid, domain FROM fingerprints'):
+            per_pid.setdefault(pid, []).append(dom)
+        lines = []
+        for pid, names in per_pid.items():
+            keep = names[:-1] if len(names) > 1 else names
+            lines.append(f'{pid} {len(keep)} {";".join(keep)}\n')
+        with open(file, 'w', encoding='utf8') as out:
+            out.writelines(lines)
 
 
 def write_flat_index(path: str, vectors: np.ndarray):

@@ -6,168 +6,199 @@ fingerprints (``-dct.npz``), with the L1 distances computed on the GPU.
 
 Same flags, same output text (src/dct-sim.py:179-211).  DCTdomain = max over all domain pairs of
 ``1 - min(L1/17000, 1)``, DCTglobal = the same for the two last (whole-protein) fingerprints
-(:12-50).  Scores are formed from the integer L1 distances with the reference's own Python
-expressions, so the printed floats are identical."""
+(:12-50).
+
+Where the reference loops over protein pairs and, inside, over domain pairs in Python, this module
+makes ONE pass on the GPU per run: the int8 L1 matrix of all fingerprints against all fingerprints
+(``dctfp_l1_matrix``) reduced per protein x protein block to (minimum, last-last) (``dctfp_block_min``).
+The three modes only differ in which blocks they print.  Scores are formed from the integer L1
+values with the reference's arithmetic (int64 / 17000 in float64), so the printed floats are identical."""
 
 from __future__ import annotations
 
 import argparse
+import sys
 import time
-from operator import itemgetter
 
 import numpy as np
 
 from .similarity import block_min, l1_matrix
 
-
-def prostSimilarity(emb1, emb2) -> float:
-    """1 - min(L1 / 17000, 1) of two fingerprints (src/dct-sim.py:12-26)."""
-    d = l1_matrix(np.asarray(emb1)[None, :], np.asarray(emb2)[None, :]).cpu().numpy()[0, 0].astype(np.int64)
-    return _sim(d)
+L1_FULL_SCALE = 17000      # src/dct-sim.py:24
+HEADER = '#prot1 prot2 sim-domain sim-global'
 
 
-def _sim(d):
-    d = d / 17000
-    d = min(d, 1)
-    return 1 - d
+def _sim(l1):
+    """1 - min(L1 / 17000, 1) for arrays of L1 values (ranking only; printing goes through ``_sim1``)."""
+    return 1 - np.minimum(np.asarray(l1, dtype=np.int64) / L1_FULL_SCALE, 1)
+
+
+def _sim1(l1):
+    """The same for one value, with the reference's scalar arithmetic (src/dct-sim.py:24-26): Python's
+    ``min`` hands back the int 1 once L1 exceeds 17000, so such a score prints as ``0``, not ``0.0``."""
+    return 1 - min(np.int64(l1) / L1_FULL_SCALE, 1)
 
 
 def _scores(mn, last):
-    """(maxs, s) as ``domain_sim`` returns them: ``maxs`` starts at int 0 and only a strictly larger
-    similarity replaces it (src/dct-sim.py:42-50)."""
-    best = _sim(np.int64(mn))
-    maxs = best if best > 0 else 0
-    return maxs, _sim(np.int64(last))
+    """(DCTdomain, DCTglobal) of one block.  The reference's running maximum starts at the int 0 and
+    is replaced only by a strictly larger similarity (:42-50)."""
+    best = _sim1(mn)
+    return (best if best > 0 else 0), _sim1(last)
+
+
+def prostSimilarity(emb1, emb2) -> float:
+    """Similarity of two single fingerprints (src/dct-sim.py:12-26)."""
+    d = l1_matrix(np.asarray(emb1)[None, :], np.asarray(emb2)[None, :]).cpu().numpy()[0, 0]
+    return _sim1(d)
 
 
 def domain_sim(dct_i: np.ndarray, dct_j: np.ndarray) -> tuple:
     """(DCTdomain, DCTglobal) of two proteins' fingerprint sets (src/dct-sim.py:28-50)."""
-    dist = l1_matrix(dct_i, dct_j)
-    mn, last = block_min(dist, [0, dct_i.shape[0]], [0, dct_j.shape[0]])
+    mn, last = block_min(l1_matrix(dct_i, dct_j), [0, dct_i.shape[0]], [0, dct_j.shape[0]])
     return _scores(mn[0, 0], last[0, 0])
 
 
 def load_dct(filename: str, asmap=True) -> tuple:
     """npz -> ({sid: fingerprints} | [fingerprints], sid) (src/dct-sim.py:52-84)."""
-    start = time.time()
-    data = np.load(filename)
-    seqid, domidx, dct_all = data['sid'], data['idx'], data['dct']
-    dct = {} if asmap else []
-    for i in range(len(seqid)):
-        ai = dct_all[domidx[i]:domidx[i + 1], :]
-        if asmap:
-            dct[seqid[i]] = ai
+    t0 = time.time()
+    with np.load(filename) as data:
+        seqid, bounds, rows = data['sid'], data['idx'], data['dct']
+    per_protein = [rows[a:b, :] for a, b in zip(bounds[:-1], bounds[1:])]
+    print(f"dct loaded for {len(seqid)} sequences, time used: {time.time() - t0:.1f}s")
+    return (dict(zip(seqid, per_protein)) if asmap else per_protein), seqid
+
+
+class Blocks:
+    """All protein-vs-protein (minimum, last-last) L1 blocks between two ``-dct.npz`` files."""
+
+    def __init__(self, file_a: str, file_b: str = None):
+        load_dct(file_a, asmap=False)                       # the reference's progress line(s)
+        if file_b is not None:
+            load_dct(file_b, asmap=False)
+        a = np.load(file_a)
+        b = a if file_b is None else np.load(file_b)
+        self.rows, self.cols = a['sid'], b['sid']
+        self.mn, self.last = block_min(l1_matrix(a['dct'], b['dct']), a['idx'], b['idx'])
+
+    def scores(self, i: int, j: int) -> tuple:
+        return _scores(self.mn[i, j], self.last[i, j])
+
+
+class Report:
+    """Result lines to a file (header first) or to stdout."""
+
+    def __init__(self, path: str = None):
+        self.path = path
+        self.out = open(path, 'w', encoding='utf8') if path else sys.stdout
+        self.line(HEADER)
+
+    def line(self, text: str):
+        self.out.write(text + '\n')
+
+    def close(self):
+        if self.path:
+            self.out.close()
+            print('results saved to', self.path)
         else:
-            dct.append(ai)
-    print(f"dct loaded for {len(seqid)} sequences, time used: {time.time() - start:.1f}s")
-    return dct, seqid
+            self.out.flush()
 
 
-def _block_scores(file_a: str, file_b: str = None):
-    """All protein-vs-protein (min, last) L1 blocks between two npz files, one GPU pass."""
-    da = np.load(file_a)
-    db = da if file_b is None else np.load(file_b)
-    dist = l1_matrix(da['dct'], db['dct'])
-    mn, last = block_min(dist, da['idx'], db['idx'])
-    return da['sid'], db['sid'], mn, last
+def _reporting(fn):
+    """The mode functions keep the reference's signature -- the last argument may be an output path or
+    ``None`` (stdout) -- and also take an open ``Report``."""
+    def run(*args):
+        *head, output = args
+        if isinstance(output, Report):
+            return fn(*head, output)
+        report = Report(output)
+        try:
+            return fn(*head, report)
+        finally:
+            report.close()
+    run.__doc__, run.__name__ = fn.__doc__, fn.__name__
+    return run
 
 
-def _emit(line: str, output: str):
-    if output:
-        with open(output, 'a', encoding='utf8') as out:
-            out.write(line + '\n')
-    else:
-        print(line)
-
-
-def pair_sim(npzfile: str, pairfile: str, pairfound: str, output: str):
-    """Similarity of every listed protein pair (src/dct-sim.py:86-124)."""
-    load_dct(npzfile, asmap=True)
-    sid, _, mn, last = _block_scores(npzfile)
-    pos = {}
-    for i, s in enumerate(sid):
-        pos[s] = i                      # a later duplicate id wins, like the dict in load_dct
-    tot, totfound = 0, 0
-    out2 = open(pairfound, 'w', encoding='utf8') if pairfound else None
-    with open(pairfile, 'r', encoding='utf8') as inf:
-        for aline in inf:
-            if aline[0] == '#':
-                if out2:
-                    out2.write(aline)
+@_reporting
+def pair_sim(npzfile: str, pairfile: str, pairfound: str, report: Report):
+    """Similarity of every listed protein pair (src/dct-sim.py:86-124).  Lines starting with ``#``
+    are comments (copied to ``pairfound``); pairs with an unknown protein are counted, not printed."""
+    blk = Blocks(npzfile)
+    where = {name: i for i, name in enumerate(blk.rows)}      # a repeated id: the later one, like a dict of arrays
+    listed = found = 0
+    kept = []
+    with open(pairfile, encoding='utf8') as pairs:
+        for text in pairs:
+            if text.startswith('#'):
+                kept.append(text)
                 continue
-            subs = aline.split()
-            s1, s2 = subs[0], subs[1]
-            tot += 1
-            if s1 in pos and s2 in pos:
-                maxs, s = _scores(mn[pos[s1], pos[s2]], last[pos[s1], pos[s2]])
-                _emit(f'{s1} {s2} {maxs} {s}', output)
-                if out2:
-                    out2.write(aline)
-                totfound += 1
-    print(f'total pair {pairfile} found {totfound} (not found: {tot - totfound})')
-    if out2:
+            first, second = text.split()[:2]
+            listed += 1
+            if first not in where or second not in where:
+                continue
+            maxs, s = blk.scores(where[first], where[second])
+            report.line(f'{first} {second} {maxs} {s}')
+            kept.append(text)
+            found += 1
+    print(f'total pair {pairfile} found {found} (not found: {listed - found})')
+    if pairfound:
+        with open(pairfound, 'w', encoding='utf8') as out:
+            out.writelines(kept)
         print(f'pairs saved to file {pairfound}')
-        out2.close()
 
 
-def db_search(npzfile: str, dbfile: str, top: int, threshold: float, output: str):
-    """Top hits of every query protein in a fingerprint database (src/dct-sim.py:126-156)."""
-    load_dct(npzfile, asmap=False)
-    load_dct(dbfile, asmap=False)
-    seqid, db_seqid, mn, last = _block_scores(npzfile, dbfile)
-    for i in range(len(seqid)):
-        results = []
-        for q in range(len(db_seqid)):
-            maxs, s = _scores(mn[i, q], last[i, q])
-            results.append([db_seqid[q], maxs, s])
-        results_sorted = sorted(results, key=itemgetter(2), reverse=True)
-        for q in range(len(db_seqid)):
-            if (q >= top) and (results_sorted[q][2] < threshold):
+@_reporting
+def db_search(npzfile: str, dbfile: str, top: int, threshold: float, report: Report):
+    """Hits of every query protein in a fingerprint database, best DCTglobal first (stable); the first
+    ``top`` always, further ones while they reach ``threshold`` (src/dct-sim.py:126-156)."""
+    blk = Blocks(npzfile, dbfile)
+    glob = _sim(blk.last)                                     # (n_query, n_db) float64
+    for i, query in enumerate(blk.rows):
+        order = np.argsort(-glob[i], kind='stable')
+        for rank, q in enumerate(order):
+            if rank >= top and glob[i, q] < threshold:
                 break
-            hit = results_sorted[q]
-            _emit(f'{seqid[i]} {hit[0]} {hit[1]} {hit[2]}', output)
+            maxs, s = blk.scores(i, q)
+            report.line(f'{query} {blk.cols[q]} {maxs} {s}')
 
 
-def all_sim(npzfile: str, output: str):
-    """All-against-all (src/dct-sim.py:158-176)."""
-    load_dct(npzfile, asmap=False)
-    seqid, _, mn, last = _block_scores(npzfile)
-    n = len(seqid)
-    for i in range(n - 1):
-        for j in range(i + 1, n):
-            maxs, s = _scores(mn[i, j], last[i, j])
-            _emit(f'{seqid[i]} {seqid[j]} {maxs:.3f} {s:.3f}', output)
+@_reporting
+def all_sim(npzfile: str, report: Report):
+    """All-against-all, upper triangle (src/dct-sim.py:158-176)."""
+    blk = Blocks(npzfile)
+    n = len(blk.rows)
+    for i, j in zip(*np.triu_indices(n, k=1)):
+        maxs, s = blk.scores(i, j)
+        report.line(f'{blk.rows[i]} {blk.rows[j]} {maxs:.3f} {s:.3f}')
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(description='protein similarity from DCT fingerprints (GPU L1)')
+    ap.add_argument('--dct', required=True, help='fingerprints of the proteins to compare (-dct.npz)')
+    ap.add_argument('--output', help='write the result lines here instead of stdout')
+    ap.add_argument('--pair', help='file of protein pairs to score (two ids per line)')
+    ap.add_argument('--pairfound', help='copy of --pair restricted to the pairs that were scored')
+    ap.add_argument('--db', help='search every protein of --dct in this -dct.npz')
+    ap.add_argument('--top', type=int, default=5, help='database search: hits always reported per query')
+    ap.add_argument('--threshold', type=float, default=0.25, help='database search: further hits down to this DCTglobal')
+    return ap
 
 
 def main(argv=None):
-    start = time.time()
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--dct', help='dct in a npz file', required=True)
-    parser.add_argument('--output', help='save results to a file', required=False)
-    parser.add_argument('--pair', help='calculate distance between the proteins in the given file', required=False)
-    parser.add_argument('--pairfound', help='pairs of proteins with similarity computed', required=False)
-    parser.add_argument('--db', help='search query dct against this db', required=False)
-    parser.add_argument('--top', help='report at most this many hits for database search', default=5, type=int)
-    parser.add_argument('--threshold', help='similarity threshold for reporting hits for database search',
-                        default=0.25, type=float)
-    args = parser.parse_args(argv)
-    if args.output:
-        with open(args.output, 'w', encoding='utf8') as out:
-            out.write('#prot1 prot2 sim-domain sim-global\n')
-    else:
-        print('#prot1 prot2 sim-domain sim-global')
-    nowt = time.time()
+    t_start = time.time()
+    args = build_parser().parse_args(argv)
+    report = Report(args.output)
+    t_work = time.time()
     if args.pair:
-        pair_sim(args.dct, args.pair, args.pairfound, args.output)
+        pair_sim(args.dct, args.pair, args.pairfound, report)
     elif args.db:
-        db_search(args.dct, args.db, args.top, args.threshold, args.output)
+        db_search(args.dct, args.db, args.top, args.threshold, report)
     else:
-        all_sim(args.dct, args.output)
-    if args.output:
-        print('results saved to', args.output)
-    end = time.time()
-    print(f'total time used {end - start:.1f}s')
-    print(f'distance calculation used {end - nowt:.1f}s')
+        all_sim(args.dct, report)
+    report.close()
+    t_end = time.time()
+    print(f'total time used {t_end - t_start:.1f}s')
+    print(f'distance calculation used {t_end - t_work:.1f}s')
 
 
 if __name__ == '__main__':

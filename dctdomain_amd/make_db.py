@@ -206,21 +206,20 @@ def run(args: argparse.Namespace) -> Database:
 
 
 def build_parser() -> argparse.ArgumentParser:
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--fafile', type=str, required=False, help='fasta file to embed')
-    parser.add_argument('--dbfile', type=str, required=True, help='db file to write to')
-    parser.add_argument('--maxlen', type=int, default=500, help='max sequence length to embed')
-    parser.add_argument('--cpu', type=int, default=1, help='number of cpus to use')
-    parser.add_argument('--gpu', type=int, required=False, help='number of gpus to use')
-    parser.add_argument('--noindex', action='store_true', help='toggle for not creating index')
-    parser.add_argument('--nonpz', action='store_true', help='toggle for not saving fingerprints')
-    parser.add_argument('--nodom', action='store_true', help='toggle for not writing domains')
-    parser.add_argument('--out', type=str, default='', help='print progress to file')
-    # additions of this build
-    parser.add_argument('--model', choices=['esm', 'synthetic'], default='esm',
-                        help='language model: fair-esm ESM-2 (as the reference) or the synthetic stand-in')
-    parser.add_argument('--flush', type=int, default=1024, help='proteins per batched fingerprint call')
-    return parser
+    """The reference's flags (src/make_db.py:167-177: names, types, defaults) + ``--model`` / ``--flush``."""
+    ap = argparse.ArgumentParser(description='FASTA -> fingerprint database (.db, -dct.npz, .dom, .index) on MI355X')
+    ap.add_argument('--dbfile', required=True, help='database to create or resume (name without extension)')
+    ap.add_argument('--fafile', help='proteins to add (.fa / .fasta); omit to resume an existing database')
+    ap.add_argument('--out', default='', help='progress log file (default: console)')
+    ap.add_argument('--maxlen', type=int, default=500, help='longest window given to the language model')
+    ap.add_argument('--cpu', type=int, default=1, help='host threads for RecCut')
+    ap.add_argument('--gpu', type=int, help='GPU worker processes (one per device)')
+    for flag, what in (('--noindex', 'the FAISS .index'), ('--nonpz', 'the -dct.npz'), ('--nodom', 'the .dom')):
+        ap.add_argument(flag, action='store_true', help=f'do not write {what}')
+    ap.add_argument('--model', choices=['esm', 'synthetic'], default='esm',
+                    help='language model: fair-esm ESM-2 (as the reference) or the synthetic stand-in')
+    ap.add_argument('--flush', type=int, default=1024, help='proteins per batched fingerprint call')
+    return ap
 
 
 def main(argv=None):

@@ -21,9 +21,12 @@ from .similarity import l1_matrix, row_select
 
 
 def _load_all(db: Database):
-    rows = db.cur.execute(""" SELECT vid, pid, domain, fingerprint FROM fingerprints """).fetchall()
-    fps = np.array([np.load(BytesIO(r[3]), allow_pickle=True) for r in rows], dtype=np.int8)
-    return rows, fps
+    """Every fingerprint row of a database as ((vid, pid, domain) tuples, int8 matrix), table order."""
+    meta, blobs = [], []
+    for vid, pid, domain, blob in db.cur.execute('SELECT vid, pid, domain, fingerprint FROM fingerprints'):
+        meta.append((vid, pid, domain))
+        blobs.append(np.load(BytesIO(blob), allow_pickle=True))
+    return meta, np.array(blobs, dtype=np.int8)
 
 
 def search(query_rows, query_fps, db_rows, db_fps, khits: int):
@@ -60,16 +63,23 @@ def search_db(args: argparse.Namespace, query_db: str, fp_db: str):
     fdb.close()
 
 
+def build_parser() -> argparse.ArgumentParser:
+    """Flags of src/query_db.py:94-110, plus ``--model`` (see make_db)."""
+    ap = argparse.ArgumentParser(description='nearest database fingerprints of every query protein (GPU L1)')
+    for flag, kind, default, text in (('--maxlen', int, 500, 'longest window given to the language model'),
+                                      ('--khits', int, 100, 'hits reported per query protein'),
+                                      ('--cpu', int, 1, 'host processes for RecCut'),
+                                      ('--gpu', int, False, 'GPU worker processes')):
+        ap.add_argument(flag, type=kind, default=default, help=text)
+    ap.add_argument('--query', required=True, help='query proteins: FASTA (.fa/.fasta) or an existing .db')
+    ap.add_argument('--db', required=True, help='database to search (.db)')
+    ap.add_argument('--out', default=False, help='write the hit lines here instead of the console')
+    ap.add_argument('--model', choices=['esm', 'synthetic'], default='esm')
+    return ap
+
+
 def main(argv=None):
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--query', type=str, required=True, help='can be .fa or .db file')
-    parser.add_argument('--db', type=str, required=True, help='fingerprint database (.db)')
-    parser.add_argument('--out', type=str, default=False, help='output file')
-    parser.add_argument('--maxlen', type=int, default=500, help='max sequence length to embed')
-    parser.add_argument('--khits', type=int, default=100, help='number of hits to return')
-    parser.add_argument('--cpu', type=int, default=1, help='number of cpus to use')
-    parser.add_argument('--gpu', type=int, default=False, help='number of gpus to use')
-    parser.add_argument('--model', choices=['esm', 'synthetic'], default='esm')
+    parser = build_parser()
     args = parser.parse_args(argv)
     if args.out:
         logging.basicConfig(level=logging.INFO, filename=args.out, filemode='w', format='%(message)s', force=True)
