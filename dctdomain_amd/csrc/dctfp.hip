@@ -160,7 +160,13 @@ struct dctfp_ctx {
     hipEvent_t ev_a[kMaxSlots] = {}, ev_b[kMaxSlots] = {};
     int ensure_side() {
         if (side) return DCTFP_OK;
+#ifdef DCTFP_SIDE_HIGH_PRIO  // A/B switch: stage B's stream at the highest priority
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        hipError_t e = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi);
+#else
         hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+#endif
         if (e != hipSuccess) { side = nullptr; g_err = std::string("hipStreamCreate: ") + hipGetErrorString(e); return DCTFP_ERR_HIP; }
         for (int i = 0; i < kMaxSlots; ++i) {
             if (hipEventCreateWithFlags(&ev_a[i], hipEventDisableTiming) != hipSuccess ||
@@ -176,7 +182,7 @@ struct dctfp_ctx {
     Staging staging[2];
     int flip = 0;
     DevBuf ws;       // yprime
-    int64_t opt_fuse = 1, opt_pack_y = 1;
+    int64_t opt_fuse = 1, opt_pack_y = 1, opt_a_lds_pad = 0, opt_b_variant = 0;
     DevBuf scratch;  // generic idct_quant fs
     std::map<std::pair<int, int>, StEntry> st_cache;
     uint64_t tick = 0;
@@ -299,6 +305,7 @@ struct AParams {
     int ldy;
     int n_slabs;
     unsigned grid;
+    unsigned dyn_lds;  // unused dynamic LDS per workgroup: caps the workgroups per CU (option a_lds_pad)
     hipStream_t stream;
 };
 
@@ -306,11 +313,11 @@ template <typename T, int N, int VEC, int WAVES, int UNROLL>
 void launch_a_impl(const AParams& p) {
     static const InvTab<N> inv = make_inv<N>();
     if (p.fused)
-        hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, true>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
+        hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, true>), dim3(p.grid), dim3(WAVES * 64), p.dyn_lds, p.stream,
                            p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld, p.ldy, p.n_slabs,
                            inv);
     else
-        hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, false>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
+        hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, false>), dim3(p.grid), dim3(WAVES * 64), p.dyn_lds, p.stream,
                            p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld, p.ldy, p.n_slabs,
                            inv);
 }
@@ -364,7 +371,7 @@ void launch_a(const AParams& p, int dtype, int vec, int n, int waves, int unroll
     }
 }
 
-void launch_b_mfma(int nt, bool packed, unsigned grid, hipStream_t s, const char* yp, int64_t job_bytes, int64_t rows,
+void launch_b_mfma(int variant, int nt, bool packed, unsigned grid, hipStream_t s, const char* yp, int64_t job_bytes, int64_t rows,
                    int ldy, const double* st, const JobB* jobs, int n, int m, int8_t* out) {
 #define DCTFP_B_CASE(NT)                                                                                             \
     case NT:                                                                                                         \
@@ -375,6 +382,11 @@ void launch_b_mfma(int nt, bool packed, unsigned grid, hipStream_t s, const char
             hipLaunchKernelGGL((stage_b_mfma_kernel<NT, false>), dim3(grid), dim3(DCTFP_B_WG_WAVES * 64), 0, s, yp, job_bytes, rows,   \
                                ldy, st, jobs, n, m, out);                                                            \
         break;
+    if (variant == 1 && nt == 5 && packed) {  // option b_variant (A/B): 32-row LDS stages, 138 VGPRs
+        hipLaunchKernelGGL((stage_b_mfma_kernel<5, true, 32, 2>), dim3(grid), dim3(DCTFP_B_WG_WAVES * 64), 0, s, yp, job_bytes, rows, ldy,
+                           st, jobs, n, m, out);
+        return;
+    }
     switch (nt) {
         DCTFP_B_CASE(1)
         DCTFP_B_CASE(2)
@@ -493,6 +505,12 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         ctx->opt_pack_y = value ? 1 : 0;
     } else if (n == "fuse") {
         ctx->opt_fuse = value ? 1 : 0;
+    } else if (n == "b_variant") {
+        if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "b_variant must be 0 or 1");
+        ctx->opt_b_variant = value;
+    } else if (n == "a_lds_pad") {
+        if (value < 0 || value > 32768) return fail(DCTFP_ERR_INVALID, "a_lds_pad must be 0..32768 bytes");
+        ctx->opt_a_lds_pad = value;
     } else if (n == "overlap") {
         if (value < 1 || value > kMaxSlots) return fail(DCTFP_ERR_INVALID, "overlap must be 1..%d", kMaxSlots);
         ctx->opt_overlap = value;
@@ -515,6 +533,8 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     else if (n == "a_unroll") *value = ctx->opt_a_unroll;
     else if (n == "overlap") *value = ctx->opt_overlap;
     else if (n == "fuse") *value = ctx->opt_fuse;
+    else if (n == "a_lds_pad") *value = ctx->opt_a_lds_pad;
+    else if (n == "b_variant") *value = ctx->opt_b_variant;
     else if (n == "pack_y") *value = ctx->opt_pack_y;
     else if (n == "profile") *value = ctx->opt_profile;
     else if (n == "workspace_mb") *value = ctx->opt_ws_mb;
@@ -904,6 +924,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 ap.n_slabs = n_slabs;
                 ap.grid = (unsigned)(ck.wn * n_slabs);
                 ap.stream = stream;
+                ap.dyn_lds = (unsigned)ctx->opt_a_lds_pad;
                 int waves = (int)ctx->opt_a_waves;
                 if (waves == 0) {  // auto: short walks want more, smaller workgroups per CU
                     waves = avg_rows >= 320 ? 8 : (avg_rows >= 160 ? 4 : 2);
@@ -923,7 +944,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             if (rc) return rc;
             if (ctx->opt_stage_b == 1) {
                 const int64_t rows = jn * n;
-                launch_b_mfma(st->cp / 16, packed, (unsigned)((rows + DCTFP_B_WG_WAVES * 16 - 1) / (DCTFP_B_WG_WAVES * 16)), sb, yprime, (int64_t)job_bytes, rows, ldy,
+                launch_b_mfma((int)ctx->opt_b_variant, st->cp / 16, packed, (unsigned)((rows + DCTFP_B_WG_WAVES * 16 - 1) / (DCTFP_B_WG_WAVES * 16)), sb, yprime, (int64_t)job_bytes, rows, ldy,
                               st->dev, djb + j0, n, m, out);
             } else {
                 hipLaunchKernelGGL(stage_b_valu_kernel, dim3((unsigned)jn), dim3(256), 0, sb, (const double*)yprime, ldy, g.n_cols,

@@ -358,20 +358,19 @@ __device__ inline int8_t quant127(double num, double den, bool bad) {
 #ifndef DCTFP_B_WG_WAVES
 #define DCTFP_B_WG_WAVES 4  // waves (16-row tiles) per stage-B workgroup (A/B: tools/ab_build_run.sh)
 #endif
-#ifndef DCTFP_B_MIN_WAVES
-#define DCTFP_B_MIN_WAVES 2  // register budget of stage B as waves per SIMD (A/B: tools/ab_build_run.sh)
+#ifndef DCTFP_B_KB
+#define DCTFP_B_KB 16  // K rows of St per LDS stage
 #endif
-template <int NT, bool PACKED>
-__global__ __launch_bounds__(DCTFP_B_WG_WAVES * 64, DCTFP_B_MIN_WAVES) void stage_b_mfma_kernel(const char* __restrict__ ypb, int64_t job_bytes,
+// Register budget as waves per SIMD: up to 5 column tiles (m <= 80, the reference's setting) fit 96 VGPRs with
+// 16-row LDS stages -- the footprint of a fused stage-A wave, so a stage-B wave fits wherever one of those leaves.
+constexpr int stage_b_min_waves(int nt) { return nt <= 5 ? 5 : (nt <= 7 ? 3 : 2); }
+template <int NT, bool PACKED, int KB = DCTFP_B_KB, int MINW = stage_b_min_waves(NT)>
+__global__ __launch_bounds__(DCTFP_B_WG_WAVES * 64, MINW) void stage_b_mfma_kernel(const char* __restrict__ ypb, int64_t job_bytes,
                                                             int64_t n_rows_total, int ldy, const double* __restrict__ st,
                                                             const JobB* __restrict__ jobs, int n, int m,
                                                             int8_t* __restrict__ out) {
     constexpr int CP = NT * 16;
     constexpr int LDS_LD = CP + 4;
-#ifndef DCTFP_B_KB
-#define DCTFP_B_KB 32
-#endif
-    constexpr int KB = DCTFP_B_KB;  // K rows of St per LDS stage
     constexpr int NQ = KB / 16;     // 16-deep A fragments per stage
     __shared__ double bs[KB][LDS_LD];
 

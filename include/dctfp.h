@@ -185,6 +185,9 @@ int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_
  *   "pack_y"       1 (default) = n = 3: the scratch between the kernels holds {0, t, 1} as one float64 + 2-bit
  *                  states per channel (9 bytes instead of 24)
  *   "fuse"         1 (default) = proteins given as parts + whole protein are streamed once
+ *   "b_variant"    0 (default) = stage B with 16-row LDS stages inside 96 VGPRs; 1 = 32-row stages, 138 VGPRs (m <= 80)
+ *   "a_lds_pad"    bytes of unused LDS added to every stage-A workgroup (0 = none): caps the stage-A workgroups
+ *                  per CU so that a stage-B workgroup always finds room beside them (measurement knob)
  *   "profile"      1 = bracket the kernels with hipEvents (see dctfp_profile)
  *   "workspace_mb" cap of the float64 scratch between the kernels */
 int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value);
