@@ -799,23 +799,45 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         int slots = 1;
         int64_t sub = 1;
         if (!trivial) {
-            int64_t cap_jobs = std::max<int64_t>(1, (int64_t)(((size_t)ctx->opt_ws_mb << 20) / job_bytes));
-            cap_jobs = std::min<int64_t>(cap_jobs, n_jobs);
-            if (ctx->opt_overlap > 1 && n_jobs >= 2048 && cap_jobs >= 2048) slots = (int)std::min<int64_t>(ctx->opt_overlap, kMaxSlots);
-            sub = (cap_jobs + slots - 1) / slots;
-            sub = std::min<int64_t>(sub, (int64_t)0x7fffffff / n_slabs);
-            sub = std::max<int64_t>(sub, 1);
+            const int64_t budget_jobs = std::max<int64_t>(1, (int64_t)(((size_t)ctx->opt_ws_mb << 20) / job_bytes));
+            if (ctx->opt_overlap > 1 && n_jobs >= 2048 && budget_jobs >= 2048) slots = (int)std::min<int64_t>(ctx->opt_overlap, kMaxSlots);
             int64_t max_group = 1;
             if (fuse)
                 for (int64_t d = 0; d < n_domains; ++d) max_group = std::max<int64_t>(max_group, d - grp_start[d] + 1);
-            sub = std::max<int64_t>(sub, max_group);  // a group always fits one region
-            int64_t nw = 0;
-            for (int64_t j0 = 0; j0 < n_jobs;) {
-                int64_t j1 = std::min<int64_t>(j0 + sub, n_jobs);
-                if (fuse && j1 < n_jobs) {
-                    const int64_t d = j1 % n_domains;
-                    if (d != 0 && grp_start[d] < d) j1 -= d - grp_start[d];  // back to the group's first job
+            // jobs one ring region may hold (a fused group always fits one region)
+            int64_t region = std::max<int64_t>(1, budget_jobs / slots);
+            region = std::min<int64_t>(region, (int64_t)0x7fffffff / n_slabs);
+            region = std::max<int64_t>(region, max_group);
+            // Chunk boundaries: equal shares (fixed-size cuts would leave a short extra chunk whose stage B runs on its
+            // own at the end).  With a side stream the last chunk gets half a share: its stage B is the only one that
+            // no stage A hides.  When the scratch budget is the limit: as many equal chunks as needed.
+            int64_t nck = slots;
+            double shares = slots > 1 ? (double)slots - 0.5 : 1.0;
+            if ((int64_t)((double)n_jobs / shares) + max_group + 1 > region) {
+                nck = (n_jobs + region - 1) / region;
+                shares = (double)nck;
+            }
+            auto group_start = [&](int64_t j) {  // a chunk never splits a fused group
+                if (fuse && j < n_jobs) {
+                    const int64_t d = j % n_domains;
+                    if (d != 0 && grp_start[d] < d) j -= d - grp_start[d];
                 }
+                return j;
+            };
+            std::vector<int64_t> cuts;
+            for (int64_t k = 1; k < nck; ++k) {
+                const int64_t prev = cuts.empty() ? 0 : cuts.back();
+                int64_t j1 = std::min<int64_t>((int64_t)((double)n_jobs * (double)k / shares + 0.5), n_jobs);
+                j1 = group_start(std::min<int64_t>(j1, prev + region));
+                if (j1 > prev && j1 < n_jobs) cuts.push_back(j1);
+            }
+            cuts.push_back(n_jobs);
+            int64_t nw = 0;
+            size_t next_cut = 0;
+            for (int64_t j0 = 0; j0 < n_jobs;) {
+                while (cuts[next_cut] <= j0) ++next_cut;
+                const int64_t j1 = std::max<int64_t>(j0 + 1, group_start(std::min<int64_t>(cuts[next_cut], j0 + region)));
+                sub = std::max<int64_t>(sub, j1 - j0);
                 Chunk ck{j0, j1, nw, 0};
                 for (int64_t j = j0; j < j1;) {
                     const int64_t d = j % n_domains;
