@@ -1,4 +1,5 @@
-"""Does stage B really run under stage A?  Same embeddings (8000 x 500 x 1280, 2 layers), domain lists with a
+"""(Every config list runs twice per case, ABAB: the first config after a table change is ~1 % slower.)
+Does stage B really run under stage A?  Same embeddings (8000 x 500 x 1280, 2 layers), domain lists with a
 growing number of fingerprints per byte; sweeps the stage-A launch shape and an LDS pad that caps the stage-A
 workgroups per CU so that one stage-B workgroup always finds room (option a_lds_pad)."""
 import os, sys, time
@@ -38,7 +39,7 @@ if workload:
 for name, table in tables.items():
     out = torch.empty((table.n_domains, 480), dtype=torch.int8, device=dev)
     ref = None
-    for waves, pad, ov, bv in configs:
+    for waves, pad, ov, bv in configs + configs:
         ctx.set_option('a_waves', waves); ctx.set_option('a_lds_pad', pad); ctx.set_option('overlap', ov); ctx.set_option('b_variant', bv)
         for _ in range(3):
             dd.quantize_batch(lbs, table, out=out, ctx=ctx)
