@@ -809,14 +809,11 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             region = std::min<int64_t>(region, (int64_t)0x7fffffff / n_slabs);
             region = std::max<int64_t>(region, max_group);
             // Chunk boundaries: equal shares (fixed-size cuts would leave a short extra chunk whose stage B runs on its
-            // own at the end).  With a side stream the last chunk gets half a share: its stage B is the only one that
-            // no stage A hides.  When the scratch budget is the limit: as many equal chunks as needed.
+            // own at the end); when the scratch budget is the limit, as many equal chunks as needed.  (A half-size
+            // last chunk -- its stage B is the only one no stage A hides -- was measured: no difference.)
             int64_t nck = slots;
-            double shares = slots > 1 ? (double)slots - 0.5 : 1.0;
-            if ((int64_t)((double)n_jobs / shares) + max_group + 1 > region) {
-                nck = (n_jobs + region - 1) / region;
-                shares = (double)nck;
-            }
+            if (n_jobs / nck + max_group + 1 > region) nck = (n_jobs + region - 1) / region;
+            const double shares = (double)nck;
             auto group_start = [&](int64_t j) {  // a chunk never splits a fused group
                 if (fuse && j < n_jobs) {
                     const int64_t d = j % n_domains;
