@@ -4,4 +4,4 @@ python bench.py 2>/dev/null
 python bench.py --workload c3 --cpu-seconds 0 2>/dev/null
 python bench.py --workload c4 --n-seq 12000 --cpu-seconds 0 2>/dev/null
 python bench.py --workload c5 --n-seq 40000 --cpu-seconds 0 2>/dev/null
-python bench.py --storage f16 --cpu-seconds 0 2>/dev/null
+python bench.py --storage float16 --cpu-seconds 0 2>/dev/null
