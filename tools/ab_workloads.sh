@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/ab_prefetch.sh "<flags of build B>"   -- A/B (A = default build) on the c5, c4 and c2 workloads
+# usage: tools/ab_workloads.sh "<flags of build B>"   -- A/B (A = default build) on the c5, c4 and c2 workloads
 set -e
 for w in c5 c4 c2; do
   n=10000; [ $w = c5 ] && n=40000; [ $w = c4 ] && n=4000
