@@ -228,6 +228,7 @@ def main():
                          'whole_path_GBps': value / world * bytes_per_fp / 1e9},
             'cpu_baseline': cpu_baseline,
             'parity': parity,
+            'per_layer_fingerprints_per_s': value * args.layers,   # 240-byte matrix fingerprints, same GB/s
         }
         print(json.dumps(line), flush=True)
     if world > 1:
