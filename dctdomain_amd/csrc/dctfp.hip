@@ -182,7 +182,7 @@ struct dctfp_ctx {
     Staging staging[2];
     int flip = 0;
     DevBuf ws;       // yprime
-    int64_t opt_fuse = 1, opt_pack_y = 1, opt_a_lds_pad = 0, opt_b_variant = 0;
+    int64_t opt_fuse = 1, opt_pack_y = 1, opt_a_lds_pad = 0, opt_b_variant = 0, opt_a_alt = 0;
     DevBuf scratch;  // generic idct_quant fs
     std::map<std::pair<int, int>, StEntry> st_cache;
     uint64_t tick = 0;
@@ -305,6 +305,7 @@ struct AParams {
     int ldy;
     int n_slabs;
     unsigned grid;
+    bool alt;          // experimental twin of the kernel (option a_alt)
     unsigned dyn_lds;  // unused dynamic LDS per workgroup: caps the workgroups per CU (option a_lds_pad)
     hipStream_t stream;
 };
@@ -312,6 +313,20 @@ struct AParams {
 template <typename T, int N, int VEC, int WAVES, int UNROLL>
 void launch_a_impl(const AParams& p) {
     static const InvTab<N> inv = make_inv<N>();
+    // the experimental twin exists for the main configuration only (float32, 16 B per lane, n = 3, 4 rows in flight)
+    if constexpr (__is_same(T, float) && N == 3 && VEC == 4 && UNROLL == 4 && (WAVES == 2 || WAVES == 4 || WAVES == 8)) {
+        if (p.alt) {
+            if (p.fused)
+                hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, true, true>), dim3(p.grid), dim3(WAVES * 64), p.dyn_lds,
+                                   p.stream, p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld,
+                                   p.ldy, p.n_slabs, inv);
+            else
+                hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, false, true>), dim3(p.grid), dim3(WAVES * 64), p.dyn_lds,
+                                   p.stream, p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld,
+                                   p.ldy, p.n_slabs, inv);
+            return;
+        }
+    }
     if (p.fused)
         hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, true>), dim3(p.grid), dim3(WAVES * 64), p.dyn_lds, p.stream,
                            p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld, p.ldy, p.n_slabs,
@@ -505,6 +520,8 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         ctx->opt_pack_y = value ? 1 : 0;
     } else if (n == "fuse") {
         ctx->opt_fuse = value ? 1 : 0;
+    } else if (n == "a_alt") {
+        ctx->opt_a_alt = value ? 1 : 0;
     } else if (n == "b_variant") {
         if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "b_variant must be 0 or 1");
         ctx->opt_b_variant = value;
@@ -535,6 +552,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     else if (n == "fuse") *value = ctx->opt_fuse;
     else if (n == "a_lds_pad") *value = ctx->opt_a_lds_pad;
     else if (n == "b_variant") *value = ctx->opt_b_variant;
+    else if (n == "a_alt") *value = ctx->opt_a_alt;
     else if (n == "pack_y") *value = ctx->opt_pack_y;
     else if (n == "profile") *value = ctx->opt_profile;
     else if (n == "workspace_mb") *value = ctx->opt_ws_mb;
@@ -944,6 +962,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 ap.grid = (unsigned)(ck.wn * n_slabs);
                 ap.stream = stream;
                 ap.dyn_lds = (unsigned)ctx->opt_a_lds_pad;
+                ap.alt = ctx->opt_a_alt != 0;
                 int waves = (int)ctx->opt_a_waves;
                 if (waves == 0) {  // auto: short walks want more, smaller workgroups per CU
                     waves = avg_rows >= 320 ? 8 : (avg_rows >= 160 ? 4 : 2);

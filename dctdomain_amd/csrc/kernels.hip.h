@@ -133,12 +133,23 @@ __device__ inline double raw_elem(const R& r, int v) {
     }
 }
 
+// Stores of stage A's results (Y').  They are 0.5 % of the bytes the kernel moves, but as ordinary write-back
+// stores they cost 8 % of its time at C2 and up to 30 % on 25-row jobs: with the stores removed (arithmetic kept) the
+// kernel streams at 7.0 TB/s for every job length, and issuing the same stores at the start of the workgroup
+// instead of its end changes nothing -- it is the write traffic, not a wait (profiles/r01/stage_a_store_experiments.txt).
+// Written through at agent scope (`sc1`) they cost about half of that; nt and sc0 sc1 measure the same within 1 %.
+template <bool WRITE_BACK = false, typename V>
+__device__ inline void store_through(V* p, V v) {
+    if constexpr (WRITE_BACK) *p = v;  // the ordinary store, kept for the A/B twin (option a_alt)
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------
 // Stage-A epilogue of one channel: resample the K-1 accumulated coefficients to N points,
 // min-max scale them (scale(): src/fingerprint.py:110-123, applied per channel at :139-140)
 // and store Y'[j][col], j < N.  Padding columns (col >= n_cols) are written as 0.
 // ---------------------------------------------------------------------------
-template <int N>
+template <int N, bool WB = false>
 __device__ inline void finish_channel(const double (&f)[N > 1 ? N - 1 : 1], const InvTab<N>& inv, double* __restrict__ o,
                                       int ldy, bool pad, bool packed, void* pk) {
     constexpr int NK = N - 1;
@@ -176,8 +187,8 @@ __device__ inline void finish_channel(const double (&f)[N > 1 ? N - 1 : 1], cons
                 t = 0.0;
                 code = 0;
             }
-            *o = t;
-            *reinterpret_cast<uint8_t*>(pk) = (uint8_t)code;
+            store_through<WB>(o, t);
+            store_through<WB>(reinterpret_cast<uint8_t*>(pk), (uint8_t)code);
             return;
         }
     }
@@ -185,7 +196,7 @@ __device__ inline void finish_channel(const double (&f)[N > 1 ? N - 1 : 1], cons
     for (int j = 0; j < N; ++j) {
         double z = bad ? __builtin_nan("") : (y[j] - mn) / den;
         if (pad) z = 0.0;
-        o[(size_t)j * ldy] = z;
+        store_through<WB>(o + (size_t)j * ldy, z);
     }
 }
 
@@ -215,7 +226,8 @@ struct Walk {
     uint32_t reserved;
 };
 
-template <typename T, int N, int VEC, int WAVES, int UNROLL, bool FUSED>
+// ALT = twin of the kernel for in-process A/B (option a_alt, tools/overlap_probe.py): here, ordinary write-back stores
+template <typename T, int N, int VEC, int WAVES, int UNROLL, bool FUSED, bool ALT = false>
 __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restrict__ jobs,
                                                               const Walk* __restrict__ walks,
                                                               const PieceA* __restrict__ pieces,
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
                 f[k] = s;
             }
             char* __restrict__ jb = yprime + (size_t)job_id * job_bytes;
-            finish_channel<N>(f, inv, reinterpret_cast<double*>(jb) + col, ldy, col >= n_cols, packed != 0,
+            finish_channel<N, ALT>(f, inv, reinterpret_cast<double*>(jb) + col, ldy, col >= n_cols, packed != 0,
                               jb + (size_t)ldy * sizeof(double) + col);
         }
     };
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(DCTFP_B_WG_WAVES * 64, MINW) void stage_b_mfma_kern
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int col = t * 16 + r16;
-                if (col < m) o[col] = quant127(acc[t][i] - mn, den, bad != 0);
+                if (col < m) o[col] = quant127(acc[t][i] - mn, den, bad != 0);  // (written through: no difference)
             }
         }
     }
