@@ -186,6 +186,8 @@ int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_
  *                  states per channel (9 bytes instead of 24)
  *   "fuse"         1 (default) = proteins given as parts + whole protein are streamed once
  *   "b_variant"    0 (default) = stage B with 16-row LDS stages inside 96 VGPRs; 1 = 32-row stages, 138 VGPRs (m <= 80)
+ *   "a_alt"        1 = launch the A/B twin of the stage-A kernel (float32, 16 B per lane, n = 3): ordinary write-back
+ *                  stores of Y' instead of write-through ones (measurement knob, same results)
  *   "a_lds_pad"    bytes of unused LDS added to every stage-A workgroup (0 = none): caps the stage-A workgroups
  *                  per CU so that a stage-B workgroup always finds room beside them (measurement knob)
  *   "profile"      1 = bracket the kernels with hipEvents (see dctfp_profile)
