@@ -13,7 +13,7 @@ import time
 
 
 def _worker(args):
-    seed, n_rows, n_cols, n_layers, qdim, seconds = args
+    seed, n_rows, n_cols, n_layers, qdim, seconds, form = args
     os.environ['OMP_NUM_THREADS'] = '1'
     os.environ['OPENBLAS_NUM_THREADS'] = '1'
     import numpy as np
@@ -25,11 +25,12 @@ def _worker(args):
                    + 5 * rng.standard_normal(n_cols)).astype(np.float32) for _ in range(n_layers)]
         pool.append(layers)
     dom = [f'1-{n_rows}']
-    orc.quantize(pool[0], dom, qdim)          # warm-up
+    quantize = orc.quantize if form == 'faithful' else orc.quantize_matrix
+    quantize(pool[0], dom, qdim)              # warm-up
     done = 0
     t0 = time.perf_counter()
     while True:
-        orc.quantize(pool[done % len(pool)], dom, qdim)
+        quantize(pool[done % len(pool)], dom, qdim)
         done += 1
         el = time.perf_counter() - t0
         if el >= seconds:
@@ -59,16 +60,29 @@ def usable_cores(cap=64):
     return max(1, min(n, cap))
 
 
-def run(n_rows=500, n_cols=1280, n_layers=2, qdim=(3, 80, 3, 80), seconds=12.0, procs=None):
-    """Returns dict(value=fingerprints/s over all workers, cores=procs, sample=...)."""
+def _timed(pool, procs, n_rows, n_cols, n_layers, qdim, seconds, form):
+    res = pool.map(_worker, [(100 + i, n_rows, n_cols, n_layers, list(qdim), seconds, form) for i in range(procs)])
+    return sum(r[0] for r in res), sum(r[0] / r[1] for r in res)
+
+
+def run(n_rows=500, n_cols=1280, n_layers=2, qdim=(3, 80, 3, 80), seconds=12.0, procs=None, matrix_seconds=4.0):
+    """Returns dict(value=fingerprints/s over all workers, cores=procs, sample=...).  ``value`` is the faithful form (what
+    the reference runs); ``matrix_form`` is the same result computed the way a tuned CPU code would (two small float64
+    matrix products per layer through numpy/BLAS, one thread per process) -- the fairer "good CPU" line of SURVEY 8d."""
     import multiprocessing as mp
     if procs is None:
         procs = usable_cores()
     ctx = mp.get_context('spawn')
     with ctx.Pool(procs) as pool:
-        res = pool.map(_worker, [(100 + i, n_rows, n_cols, n_layers, list(qdim), seconds) for i in range(procs)])
-    total = sum(r[0] for r in res)
-    rate = sum(r[0] / r[1] for r in res)
-    return {'value': rate, 'unit': 'fingerprints/s', 'cores': procs, 'kind': 'port',
-            'sample': f'{total} fingerprints (L={n_rows}, D={n_cols}, {n_layers} layers, qdim {list(qdim)}) in '
-                      f'{seconds:.0f} s on {procs} processes; oracle faithful form (scipy.fft dct/idct + per-row scale loop)'}
+        total, rate = _timed(pool, procs, n_rows, n_cols, n_layers, qdim, seconds, 'faithful')
+        extra = None
+        if matrix_seconds > 0:
+            mtotal, mrate = _timed(pool, procs, n_rows, n_cols, n_layers, qdim, matrix_seconds, 'matrix')
+            extra = {'value': mrate, 'unit': 'fingerprints/s', 'cores': procs,
+                     'sample': f'{mtotal} fingerprints in {matrix_seconds:.0f} s; oracle matrix form (numpy float64 matmul)'}
+    out = {'value': rate, 'unit': 'fingerprints/s', 'cores': procs, 'kind': 'port',
+           'sample': f'{total} fingerprints (L={n_rows}, D={n_cols}, {n_layers} layers, qdim {list(qdim)}) in '
+                     f'{seconds:.0f} s on {procs} processes; oracle faithful form (scipy.fft dct/idct + per-row scale loop)'}
+    if extra:
+        out['matrix_form'] = extra
+    return out
