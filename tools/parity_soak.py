@@ -50,6 +50,8 @@ if __name__ == '__main__':
             table = dd.PieceTable.whole_sequences([L] * bn)
             offs = np.arange(bn) * L
             got[b0:b0 + bn] = dd.quantize_batch([dd.LayerBatch(t, 3, 80, row_offsets=offs) for t in layers], table).cpu().numpy()
+            if (b0 // B) % 8 == 7:
+                print(f'  GPU side: {b0 + bn} / {n} done, {time.time() - t0:.0f} s', flush=True)
         exp = np.concatenate(async_res.get())
     bad_vals = int((got != exp).sum())
     bad_fps = int((got != exp).any(axis=1).sum())
