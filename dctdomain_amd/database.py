@@ -58,7 +58,15 @@ def _npy_bytes(vec: np.ndarray) -> bytes:
 
 
 def _npy_vector(blob: bytes) -> np.ndarray:
-    return np.load(BytesIO(blob), allow_pickle=True)
+    """The array of an ``np.save`` blob.  Blobs written by this module (or by the reference: same numpy call, same header)
+    start with a header already seen -- then the payload is taken as it is, without re-parsing the header."""
+    for (descr, shape), head in _NPY_HEADERS.items():
+        if len(blob) == len(head) + int(np.prod(shape)) * np.dtype(descr).itemsize and blob.startswith(head):
+            return np.frombuffer(blob, dtype=descr, offset=len(head)).reshape(shape)
+    vec = np.load(BytesIO(blob), allow_pickle=True)
+    if vec.ndim == 1 and vec.flags.c_contiguous:
+        _NPY_HEADERS.setdefault((vec.dtype.str, vec.shape), blob[:len(blob) - vec.nbytes])
+    return vec
 
 
 def _fasta_records(path: str) -> Iterator[Tuple[str, str]]:
@@ -215,9 +223,14 @@ class Database:
 
     def rename_vid(self):
         """vids 1..N in table order (:268-282), set-based: rows move to -1..-N first so that the
-        PRIMARY KEY stays unique, then flip sign."""
+        PRIMARY KEY stays unique, then flip sign.  The usual case -- one writer, vids consecutive from some
+        offset -- is a single shift statement."""
         vids = [v for v, in self.cur.execute('SELECT vid FROM fingerprints')]
-        if any(v != i for i, v in enumerate(vids, 1)):
+        if vids and vids[0] > 1 and all(b - a == 1 for a, b in zip(vids, vids[1:])):
+            # (a direct "vid = vid - shift" trips over the key it is about to free: measured, IntegrityError)
+            self.cur.execute('UPDATE fingerprints SET vid = -(vid - ?)', (vids[0] - 1,))
+            self.cur.execute('UPDATE fingerprints SET vid = -vid')
+        elif any(v != i for i, v in enumerate(vids, 1)):
             self.cur.executemany('UPDATE fingerprints SET vid = ? WHERE vid = ?',
                                  ((-i, v) for i, v in enumerate(vids, 1)))
             self.cur.execute('UPDATE fingerprints SET vid = -vid')
