@@ -177,7 +177,9 @@ class Database:
         ``quants[dom]`` (0..127 ints) -- a ``Fingerprint`` or anything shaped like one.  vids are
         drawn from ``counter`` (incremented first, like :216-218), under ``lock`` when one is given."""
         if counter is None:
-            counter = _Serial(self.get_last_vid())
+            # own numbering: continue right after the last vid, so that a fresh build comes out as 1..N and
+            # ``rename_vid`` has nothing to move (a caller's shared counter keeps the reference's off-by-one start)
+            counter = _Serial(self.get_last_vid() - 1)
 
         def next_vid():
             counter.value += 1
