@@ -37,8 +37,11 @@ sync(); t['embed (synthetic model + stitch)'] = time.perf_counter() - t0
 lens_l = [len(fp.seq) for fp in fps]
 maps = [reccut._contact_tensor(fp.contacts, L) for fp, L in zip(fps, lens_l)]
 sync(); t0 = time.perf_counter()
-offs, ci, cj, cv = reccut.top_contacts_batch(maps, 2.6)
-sync(); t['contact top-k (GPU) + D2H + host sort'] = time.perf_counter() - t0
+offs, ci, cj, cv = reccut.top_contacts_batch(maps, 2.6, sort=False)      # what make_db.fingerprint_batch does
+sync(); t['contact top-k (GPU) + D2H'] = time.perf_counter() - t0
+t0 = time.perf_counter()
+reccut.top_contacts_batch(maps, 2.6, sort=True)
+sync(); t['(same with the .ce ordering: host sort, only for writece)'] = time.perf_counter() - t0
 t0 = time.perf_counter()
 doms = reccut.domains_from_contacts(lens_l, offs, ci, cj, cv, threads=threads)
 t[f'RecCut in-process ({threads} threads)'] = time.perf_counter() - t0
