@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <string>
 #include <thread>
 #include <utility>
@@ -138,10 +139,20 @@ void cut_rec(const Ctx& cx, const std::vector<int>& idx, const std::vector<int>&
 
     // local dense copy in current vertex order
     std::vector<int> a((size_t)V * V);
-    for (int i = 0; i < V; ++i) {
-        const int* row = &cx.w[(size_t)idx[i] * cx.n0];
-        int* dst = &a[(size_t)i * V];
-        for (int j = 0; j < V; ++j) dst[j] = row[idx[j]];
+    {
+        // idx is a handful of runs of consecutive residues: copy run by run instead of element by element
+        std::vector<std::pair<int, int>> runs;  // (first position in idx, length)
+        for (int j = 0; j < V;) {
+            int e = j + 1;
+            while (e < V && idx[e] == idx[e - 1] + 1) ++e;
+            runs.emplace_back(j, e - j);
+            j = e;
+        }
+        for (int i = 0; i < V; ++i) {
+            const int* row = &cx.w[(size_t)idx[i] * cx.n0];
+            int* dst = &a[(size_t)i * V];
+            for (const auto& r : runs) std::memcpy(dst + r.first, row + idx[r.first], (size_t)r.second * sizeof(int));
+        }
     }
     auto A = [&](int i, int j) { return a[(size_t)i * V + j]; };
 
@@ -176,18 +187,15 @@ void cut_rec(const Ctx& cx, const std::vector<int>& idx, const std::vector<int>&
 
     // inner[i][j] = total weight inside the vertex range [i, j]  (S of the reference)
     std::vector<int> inner((size_t)V * V, 0);
-    {
-        std::vector<int> rowpref((size_t)V * V);
-        for (int i = 0; i < V; ++i) {
-            int r = 0;
-            for (int j = 0; j < V; ++j) {
-                if (j > i) r += A(i, j);
-                rowpref[(size_t)i * V + j] = r;  // sum_{b=i+1..j} a[i][b]
-            }
+    for (int i = V - 2; i >= 0; --i) {  // row i from row i + 1, both walked contiguously
+        const int* ai = &a[(size_t)i * V];
+        const int* below = &inner[(size_t)(i + 1) * V];
+        int* here = &inner[(size_t)i * V];
+        int r = 0;  // sum_{b = i+1..j} a[i][b]
+        for (int j = i + 1; j < V; ++j) {
+            r += ai[j];
+            here[j] = below[j] + r;
         }
-        for (int j = 0; j < V; ++j)
-            for (int i = j - 1; i >= 0; --i)
-                inner[(size_t)i * V + j] = inner[(size_t)(i + 1) * V + j] + rowpref[(size_t)i * V + j];
     }
     double best2 = 2.0;
     int cuts1 = 0, cuts2 = 0;
@@ -242,6 +250,18 @@ void cut_rec(const Ctx& cx, const std::vector<int>& idx, const std::vector<int>&
     cut_rec(cx, idx2, s2, d2, out);
 }
 
+// (int)(strtod("%.6f" % p) * 100 + 0.5): the text round trip only matters next to a rounding boundary
+int contact_weight(float p) {
+    const double x = (double)p * 100 + 0.5;
+    const double fl = std::floor(x);
+    // printing to 6 decimals moves x by at most 5e-5 (+ a few ulp): away from an integer by 1e-3 nothing can change
+    if (x - fl > 1e-3 && fl + 1 - x > 1e-3 && x > -2e9 && x < 2e9) return (int)x;
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.6f", (double)p);
+    const double v = strtod(buf, nullptr);
+    return (int)(v * 100 + 0.5);
+}
+
 int predict_impl(int32_t n_res, const int32_t* ci, const int32_t* cj, const float* prob, int64_t n_contacts,
                  double cut1, double cut2, std::string& text, int32_t* n_domains) {
     if (n_res <= 0 || n_contacts < 0 || (n_contacts > 0 && (!ci || !cj || !prob))) return RECCUT_ERR_INVALID;
@@ -253,14 +273,10 @@ int predict_impl(int32_t n_res, const int32_t* ci, const int32_t* cj, const floa
     Domain whole(1, Seg(0, n_res - 1));
     if (n_res >= kMinSize) {
         cx.w.assign((size_t)n_res * n_res, 0);
-        char buf[64];
         for (int64_t k = 0; k < n_contacts; ++k) {
             const int i = ci[k], j = cj[k];
             if (i < 0 || j < 0 || i >= n_res || j >= n_res) return RECCUT_ERR_INVALID;
-            // the value as the .ce file carries it: "%.6f" of the float32, parsed back as double
-            snprintf(buf, sizeof buf, "%.6f", (double)prob[k]);
-            const double v = strtod(buf, nullptr);
-            const int wgt = (int)(v * 100 + 0.5);
+            const int wgt = contact_weight(prob[k]);  // the value as the .ce file carries it
             cx.w[(size_t)i * n_res + j] = wgt;
             cx.w[(size_t)j * n_res + i] = wgt;
         }
@@ -295,6 +311,8 @@ int predict_impl(int32_t n_res, const int32_t* ci, const int32_t* cj, const floa
 }  // namespace
 
 extern "C" {
+
+int32_t reccut_contact_weight(float prob) { return contact_weight(prob); }
 
 int reccut_predict(int32_t n_res, const int32_t* ci, const int32_t* cj, const float* prob, int64_t n_contacts,
                    double cut1, double cut2, char* out, int64_t out_cap, int32_t* n_domains) {

@@ -38,6 +38,11 @@ extern "C" {
 int reccut_predict(int32_t n_res, const int32_t* ci, const int32_t* cj, const float* prob, int64_t n_contacts,
                    double cut1, double cut2, char* out, int64_t out_cap, int32_t* n_domains);
 
+/* The integer edge weight the reference derives from a contact probability: the float32 printed as "%.6f" into the
+ * .ce file (src/fingerprint.py:72), read back by the binary and turned into (int)(v*100+0.5) (src/RecCut.cpp:384).
+ * Computed without the text round trip unless the value sits within 1e-5 of a rounding boundary. */
+int32_t reccut_contact_weight(float prob);
+
 /* Many proteins on n_threads host threads.  Protein p uses contacts [offs[p], offs[p+1]) and writes
  * its string at out + p * out_stride.  rc[p] receives the per-protein return code. */
 int reccut_predict_batch(int64_t n_prot, const int32_t* n_res, const int64_t* offs, const int32_t* ci,

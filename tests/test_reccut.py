@@ -169,3 +169,20 @@ def test_gpu_topk_batch_mixed_lengths():
         np.testing.assert_array_equal(ci[a:b], oi)
         np.testing.assert_array_equal(cj[a:b], oj)
         np.testing.assert_array_equal(cv[a:b], ov)
+
+
+def test_contact_weight_matches_text_round_trip():
+    """reccut_contact_weight == (int)(strtod("%.6f" % p) * 100 + 0.5) (src/fingerprint.py:72 + src/RecCut.cpp:384),
+    checked on random probabilities and on values hugging every rounding boundary."""
+    import ctypes as C
+    from dctdomain_amd import _lib
+    lib = _lib.load_reccut()
+    lib.reccut_contact_weight.argtypes = [C.c_float]
+    lib.reccut_contact_weight.restype = C.c_int32
+    rng = np.random.default_rng(1)
+    edge = (np.arange(0, 101)[:, None] / 100.0 - 0.005 + np.linspace(-3e-6, 3e-6, 61)[None, :]).ravel().astype(np.float32)
+    vals = np.concatenate([rng.random(20000).astype(np.float32), edge, np.nextafter(edge, np.float32(1)),
+                           np.nextafter(edge, np.float32(0)),
+                           np.array([0, 1, 0.5, 1e-7, 5e-3, 0.995, -0.2, -1e-9, 2.0], dtype=np.float32)])
+    for p in vals:
+        assert lib.reccut_contact_weight(float(p)) == int(float('%.6f' % float(p)) * 100 + 0.5), float(p)
