@@ -94,14 +94,30 @@ def make_workload(args, rank, np):
     return lengths, doms, args.dim or dim
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without torchrun: start the N ranks as children of this process
+    (`python -m torch.distributed.run`, rendezvous on 127.0.0.1), pass rank 0's JSON line through and
+    return the launcher's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # Started without a launcher: be the launcher (the reference starts its own per-GPU processes too,
+        # src/make_db.py:105-116).  This parent never touches the GPU; the ranks are fresh child processes.
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
 
     # ---- CPU baseline leg first (rank 0, N = 1 only), before this process touches the GPU ----

@@ -1,0 +1,53 @@
+"""bench.py --gpus N must work however it is started: with torchrun (the driver's way) or bare, in which case it
+starts its own ranks (the reference starts its per-GPU processes itself, src/make_db.py:105-116)."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    return env
+
+
+def test_bare_gpus2_starts_its_own_ranks_cpu():
+    """No GPU here: the two child ranks must start (WORLD_SIZE = 2 each) and stop at the 'needs an MI355X' check --
+    not at the old 'launch with torch.distributed.run' refusal of the parent."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('CPU-only check')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo',
+                        '--cpu-seconds', '0', '--n-seq', '8'], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert 'launch with torch.distributed.run' not in r.stderr
+    assert r.stderr.count('bench.py needs an MI355X') >= 2, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('launcher', ['bare', 'torchrun'])
+def test_gpus2_on_one_gpu_over_gloo(launcher):
+    """Two ranks sharing the one GPU (gloo control plane): one JSON line, n_gpus 2, parity sample clean."""
+    args = ['--gpus', '2', '--backend', 'gloo', '--n-seq', '2000', '--steps', '3', '--warmup', '1', '--cpu-seconds', '0',
+            '--parity-sample', '8']
+    if launcher == 'bare':
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py')] + args
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+               '127.0.0.1', '--master-port', '29731', os.path.join(ROOT, 'bench.py')] + args
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak'
+    assert line['config']['sequences_per_gpu'] == 2000
+    assert line['parity']['mismatching_fingerprints'] == 0 and line['parity']['checked'] == 8
+    assert line['value'] > 0
