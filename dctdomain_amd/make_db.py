@@ -11,7 +11,8 @@ the host, pickles it into a ``multiprocessing.Pool`` and fingerprints one protei
 batched contact top-k, one threaded in-process RecCut call and one ``dctfp_quantize`` launch
 (``fingerprint_batch``).  ``--cpu`` sizes the RecCut thread pool, ``--gpu G`` starts one process
 per GPU over disjoint, length-balanced shards; a single writer (the parent) fills the database in
-sequence order, so the files are identical for every G.
+sequence order, one transaction per flush (``OrderedWriter``), so the files are identical for every G and an
+interrupted build resumes where it stopped (``fpcount``, src/database.py:150, :211-213).
 """
 
 from __future__ import annotations
@@ -136,14 +137,109 @@ def process_sequences(seqs, model, device, maxlen: int, cpu: int, flush: int, si
 
 
 def _gpu_worker(rank: int, n_gpu: int, shards, model_name: str, maxlen: int, cpu: int, flush: int, out_q):
-    n_dev = torch.cuda.device_count()
-    dev = torch.device('cuda', rank % max(1, n_dev))
-    torch.cuda.set_device(dev)
-    model = load_model(model_name, dev)
+    """One worker process per GPU (reference ``queue_gpu``, src/make_db.py:54-92).  Whatever happens in here, the
+    parent hears about it: results as ``('recs', rank, records)``, a Python error as ``('error', rank, traceback)`` and
+    always a closing ``('done', rank)``; a worker that dies without it (signal, abort) is noticed by ``_run_workers``."""
     try:
-        process_sequences(shards[rank], model, dev, maxlen, cpu, flush, lambda recs: out_q.put(recs))
+        n_dev = torch.cuda.device_count()
+        dev = torch.device('cuda', rank % max(1, n_dev))
+        torch.cuda.set_device(dev)
+        model = load_model(model_name, dev)
+        process_sequences(shards[rank], model, dev, maxlen, cpu, flush, lambda recs: out_q.put(('recs', rank, recs)))
+    except BaseException:       # noqa: BLE001 -- reported to the parent, which stops the build
+        import traceback
+        out_q.put(('error', rank, traceback.format_exc()))
     finally:
-        out_q.put(None)
+        out_q.put(('done', rank))
+
+
+def _run_workers(n_gpu: int, worker_args: tuple, sink, target=None, poll_s: float = 2.0):
+    """Starts one process per GPU, hands every batch of records to ``sink`` as it arrives and returns when all
+    workers have said 'done'.  A worker that reports an error, or that is gone without its closing message, ends the
+    build: the other workers are terminated and RuntimeError is raised (what was written so far stays in the
+    database, ``fpcount`` marks it, the next run resumes)."""
+    import queue as _queue
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out_q = ctx.Queue()
+    procs = [ctx.Process(target=target or _gpu_worker, args=(r, n_gpu) + tuple(worker_args) + (out_q,)) for r in range(n_gpu)]
+    for p in procs:
+        p.start()
+    finished, failure = set(), None
+    try:
+        while len(finished) < n_gpu and failure is None:
+            try:
+                item = out_q.get(timeout=poll_s)
+            except _queue.Empty:
+                for r, p in enumerate(procs):
+                    if r not in finished and not p.is_alive():
+                        # dead without a closing message; drain what it may still have queued before giving up
+                        try:
+                            while True:
+                                late = out_q.get(timeout=0.5)
+                                if late[0] == 'recs':
+                                    sink(late[2])
+                                elif late[0] == 'done':
+                                    finished.add(late[1])
+                                elif late[0] == 'error':
+                                    failure = f'GPU worker {late[1]} failed:\n{late[2]}'
+                        except _queue.Empty:
+                            pass
+                        if r not in finished and failure is None:
+                            failure = f'GPU worker {r} died (exit code {p.exitcode}) without finishing its shard'
+                continue
+            if item[0] == 'recs':
+                sink(item[2])
+            elif item[0] == 'error':
+                failure = f'GPU worker {item[1]} failed:\n{item[2]}'
+            elif item[0] == 'done':
+                finished.add(item[1])
+    finally:
+        if failure is not None or len(finished) < n_gpu:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+        for p in procs:
+            p.join(timeout=30)
+    if failure is not None:
+        raise RuntimeError(failure)
+    for r, p in enumerate(procs):
+        if p.exitcode != 0:
+            raise RuntimeError(f'GPU worker {r} exited with code {p.exitcode}')
+
+
+class OrderedWriter:
+    """The single writer of a build: records arrive per flush -- in pending order from one GPU, interleaved from
+    several -- and go into the database in pending order, one transaction per contiguous run that is complete.
+    Only what arrived ahead of its turn is held back (O(workers x flush) records), so the ``.db`` is the checkpoint
+    *during* a run as it is in the reference (commit per protein + ``fpcount``, src/database.py:211-224, :150):
+    an interrupted build resumes after the last committed protein and ends with the same files."""
+
+    def __init__(self, db: Database, pending):
+        self.db = db
+        self.order = {pid: i for i, (pid, _) in enumerate(pending)}
+        self.next = 0                 # pending index of the next protein to write
+        self.held = {}                # pending index -> record that arrived early
+        self.written = 0
+
+    def add(self, records):
+        for pid, domains, mat in records:
+            self.held[self.order[pid]] = _Rec(pid, domains, mat)
+        run = []
+        while self.next in self.held:
+            run.append(self.held.pop(self.next))
+            self.next += 1
+        if run:
+            self.db.add_fprints(run)          # one transaction
+            self.written += len(run)
+
+    def finish(self):
+        """Whatever is still held (gaps are proteins that produced no record) goes in, in pending order."""
+        if self.held:
+            run = [self.held[i] for i in sorted(self.held)]
+            self.held.clear()
+            self.db.add_fprints(run)
+            self.written += len(run)
 
 
 def run(args: argparse.Namespace) -> Database:
@@ -152,46 +248,23 @@ def run(args: argparse.Namespace) -> Database:
     db = Database(args.dbfile, args.fafile)
     print('Fingerprinting sequences...\n')
     pending = db.pending()
-    order = {pid: i for i, (pid, _) in enumerate(pending)}
     n_gpu = int(args.gpu) if args.gpu else 1
     cpu = max(1, int(args.cpu))
-    results = {}
-
-    def sink(records):
-        for pid, domains, mat in records:
-            results[pid] = _Rec(pid, domains, mat)
+    writer = OrderedWriter(db, pending)
 
     if not torch.cuda.is_available():
         raise RuntimeError('make_db needs an MI355X GPU: the fingerprint path has no CPU fallback')
     if n_gpu <= 1:
         dev = torch.device('cuda', torch.cuda.current_device())
         model = load_model(args.model, dev)
-        process_sequences(pending, model, dev, args.maxlen, cpu, args.flush, sink)
+        process_sequences(pending, model, dev, args.maxlen, cpu, args.flush, writer.add)
     else:
-        import torch.multiprocessing as mp
         from .dist import balanced_shards
         idx = balanced_shards([len(s) for _, s in pending], n_gpu)
         shards = [[pending[i] for i in ix] for ix in idx]
-        ctx = mp.get_context('spawn')
-        out_q = ctx.Queue()
-        procs = [ctx.Process(target=_gpu_worker, args=(r, n_gpu, shards, args.model, args.maxlen, cpu, args.flush, out_q))
-                 for r in range(n_gpu)]
-        for p in procs:
-            p.start()
-        done = 0
-        while done < n_gpu:
-            item = out_q.get()
-            if item is None:
-                done += 1
-            else:
-                sink(item)
-        for p in procs:
-            p.join()
-            if p.exitcode != 0:
-                raise RuntimeError(f'GPU worker exited with code {p.exitcode}')
-    # single writer, table order = pending order (ascending length) whatever the number of GPUs
-    recs = sorted(results.values(), key=lambda r: order[r.pid])
-    db.add_fprints(recs)
+        _run_workers(n_gpu, (shards, args.model, args.maxlen, cpu, args.flush), writer.add)
+    # table order = pending order (ascending length) whatever the number of GPUs
+    writer.finish()
     db.rename_vid()
     db.update_metadata()
     if not args.noindex:
