@@ -176,6 +176,36 @@ for L in (64, 120, 257):
              [dict(recipe='esm', L=L, D=640, seed=nseed()), dict(recipe='contact', L=L, D=L, seed=nseed())],
              [f'1-{L}', f'1-{L // 2}', f'{L // 2 + 1}-{L}'], [3, 80, 5, 44])
 
+# 8. BASELINE config 4 as stated: D = 2560 x RecCut-shaped domain lists (parts that tile the protein, a
+#    discontinuous part, then the whole protein '1-L' -- src/fingerprint.py:103-107) x two layers; these are the
+#    fused walks of the GPU path.  Part boundaries as RecCut emits them (multiples of nothing in particular).
+C4 = {
+    100: [['1-47', '48-100', '1-100'], ['1-30,71-100', '31-70', '1-100']],
+    374: [['1-120', '121-250', '251-374', '1-374'], ['1-88,301-374', '89-200', '201-300', '1-374'],
+          ['1-25', '26-51', '52-77', '78-374', '1-374']],
+    500: [['1-95', '96-210', '211-330,401-440', '331-400', '441-500', '1-500'], ['1-250', '251-500', '1-500'],
+          ['1-22', '23-44', '45-140,300-322', '141-299', '323-500', '1-500'], ['1-500']],
+}
+for L, lists in C4.items():
+    for n_, doms in enumerate(lists):
+        add_case(f'c4_D2560_L{L}_{n_}',
+                 [dict(recipe='esm', L=L, D=2560, seed=nseed()), dict(recipe='esm', L=L, D=2560, seed=nseed())],
+                 doms, [3, 80, 3, 80])
+# the same shapes at the other widths (fused walks at D = 640 / 1280, incl. a width that is not a multiple of 256)
+for D in (640, 1280, 1000):
+    add_case(f'c4_D{D}_L374', [dict(recipe='esm', L=374, D=D, seed=nseed()), dict(recipe='esm', L=374, D=D, seed=nseed())],
+             C4[374][1], [3, 80, 3, 80])
+    add_case(f'c4_D{D}_L500', [dict(recipe='esm', L=500, D=D, seed=nseed()), dict(recipe='esm', L=500, D=D, seed=nseed())],
+             C4[500][2], [3, 80, 3, 80])
+# many short parts (more jobs than one stage-B group of the fused kernel holds)
+edges = list(range(0, 500, 31)) + [500]
+add_case('c4_D1280_L500_17parts', [dict(recipe='esm', L=500, D=1280, seed=nseed()), dict(recipe='gauss', L=500, D=1280, seed=nseed())],
+         [f'{a + 1}-{b}' for a, b in zip(edges[:-1], edges[1:])] + ['1-500'], [3, 80, 3, 80])
+# contact map as an extra layer at the config's largest L
+add_case('contact_layer_L500',
+         [dict(recipe='esm', L=500, D=2560, seed=nseed()), dict(recipe='contact', L=500, D=500, seed=nseed())],
+         ['1-500', '1-250', '251-500'], [3, 80, 5, 44])
+
 # get_doms table ------------------------------------------------------------------
 gd = []
 xg = np.arange(100 * 4, dtype=np.float32).reshape(100, 4)

@@ -464,3 +464,107 @@ def test_randomised_shapes_against_oracle(dd):
                                               err_msg=f'case {case} seq {s} dom {dom} D={D} qd={qd} {dtype} pad={pad}')
                 row += 1
         assert row == table.n_domains
+
+
+def test_config4_batch_with_reference_goldens_inside(dd):
+    """BASELINE config 4 as stated, at scale: 2 400 proteins, D = 2560, L <= 500, RecCut-shaped domain lists
+    (parts + whole protein, discontinuous parts) through ONE quantize_batch call with fused walks, the scratch cut
+    into several chunks.  The reference-generated golden cases `c4_D2560_*` (tests/golden/make_golden.py section 8)
+    and the D = 2560 queue_cpu cases (make_golden_reccut.py) sit inside the batch -- first, last and at positions
+    that land on chunk boundaries -- and must come out bit-exact; a sample of the filler is checked against the
+    oracle; fused, unfused and small-scratch runs must agree on every byte."""
+    import json
+    import os
+    import torch
+    D = 2560
+    gold = [c for c in ALL_OK if c['id'].startswith('c4_D2560_')]
+    assert len(gold) >= 9
+    with open(os.path.join(gu.GOLD, 'reccut_golden.json')) as fh:
+        rc_cases = [c for c in json.load(fh)['cases'] if c.get('pipeline', {}).get('D') == D]
+    rc_arr = np.load(os.path.join(gu.GOLD, 'reccut_golden.npz'))
+    assert len(rc_cases) >= 8
+    members = []                                   # (layers [2 x (L, D) float32], domains, expected {key: int8})
+    for c in gold:
+        members.append((gu.build_layers(c), c['domains'], gu.expected(c)))
+    for c in rc_cases:
+        pl = c['pipeline']
+        ls = [make_input('esm', c['L'], D, sd) for sd in pl['seeds']]
+        members.append((ls, c['domains'], {k: rc_arr[f"{c['id']}/q/{i}"] for i, k in enumerate(pl['keys'])}))
+    n_seq = 2400
+    rng = np.random.default_rng(404)
+    slots = sorted(set([0, n_seq - 1] + [int(v) for v in np.linspace(1, n_seq - 2, len(members) - 2)]))
+    assert len(slots) == len(members)
+    where = dict(zip(slots, range(len(members))))
+    lens, doms = [], []
+    for s in range(n_seq):
+        if s in where:
+            ls, dm, _ = members[where[s]]
+            lens.append(ls[0].shape[0])
+            doms.append(list(dm))
+            continue
+        L = int(rng.integers(100, 501))
+        k = int(rng.integers(1, 7))
+        if k == 1:
+            lens.append(L)
+            doms.append([f'1-{L}'])
+            continue
+        cuts = sorted(set(int(c) for c in rng.integers(22, L - 22, size=k - 1)))
+        edges = [0] + cuts + [L]
+        edges = [e for i, e in enumerate(edges) if i == 0 or e == L or e - edges[i - 1] >= 22]
+        if L - edges[-2] < 22:
+            edges.pop(-2)
+        parts = [f'{a + 1}-{b}' for a, b in zip(edges[:-1], edges[1:])]
+        if len(parts) >= 3 and rng.random() < 0.3:
+            parts = [parts[-1] + ',' + parts[0]] + parts[1:-1]          # RecCut's discontinuous form: 'c-d,a-b'
+        lens.append(L)
+        doms.append(parts + [f'1-{L}'] if len(parts) > 1 else [f'1-{L}'])
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    g = torch.Generator(device='cuda')
+    g.manual_seed(44)
+    xs = []
+    for k in range(2):
+        x = torch.randn((int(sum(lens)), D), generator=g, device='cuda')
+        x = x * torch.exp(torch.randn((1, D), generator=g, device='cuda')) + 5 * torch.randn((1, D), generator=g, device='cuda')
+        x[:, 5::101] += 200.0
+        for s, mi in where.items():
+            x[int(offs[s]):int(offs[s]) + lens[s]] = torch.from_numpy(members[mi][0][k]).cuda()
+        xs.append(x)
+    table = dd.PieceTable(lens, doms)
+    assert table.n_domains * 2 >= 4 * 2048                               # enough jobs for the 4-chunk plan
+    lbs = [dd.LayerBatch(x, 3, 80, row_offsets=offs) for x in xs]
+    ctx = dd.get_context(torch.cuda.current_device())
+    assert ctx.get_option('fuse') == 1
+    out = dd.quantize_batch(lbs, table).cpu().numpy()
+    first = {}
+    for row, s in enumerate(table.owner):
+        first.setdefault(s, row)
+    # 1. the reference's own outputs
+    n_gold_rows = 0
+    for s, mi in where.items():
+        _, dm, exp = members[mi]
+        keys = table.keys[first[s]:first[s] + len(exp)]
+        assert keys == list(exp), (s, keys)
+        for i, k in enumerate(exp):
+            np.testing.assert_array_equal(out[first[s] + i], np.asarray(exp[k]).astype(np.int8), err_msg=f'slot {s} {k}')
+            n_gold_rows += 1
+    assert n_gold_rows >= 60
+    # 2. filler sample against the oracle
+    for s in [v for v in range(3, n_seq, 211) if v not in where]:
+        a, b = int(offs[s]), int(offs[s]) + lens[s]
+        q = orc.quantize([x[a:b].cpu().numpy() for x in xs], doms[s], [3, 80, 3, 80])
+        for i, k in enumerate(q):
+            np.testing.assert_array_equal(out[first[s] + i].astype(np.int64), q[k], err_msg=f'seq {s} {k}')
+    # 3. every byte: unfused path, small scratch (many chunks, groups never split)
+    old = {k: ctx.get_option(k) for k in ('fuse', 'workspace_mb')}
+    try:
+        ctx.set_option('workspace_mb', 64)
+        small = dd.quantize_batch(lbs, table).cpu().numpy()
+        ctx.set_option('fuse', 0)
+        plain = dd.quantize_batch(lbs, table).cpu().numpy()
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v)
+    np.testing.assert_array_equal(small, out)
+    np.testing.assert_array_equal(plain, out)
+    rows = out.reshape(-1, 6, 80)
+    assert ((rows == 127).sum(axis=2) == 1).all() and ((rows == 0).sum(axis=2) >= 1).all()
