@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -26,6 +27,8 @@ using namespace dctfp;
 namespace {
 
 thread_local std::string g_err;
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -129,8 +132,15 @@ struct Staging {  // pinned host buffer + the event after its last H2D copy
 
 struct StEntry {  // stage-B basis  St[d][c] (ldy x cp), zero padded
     double* dev = nullptr;
+    double* frag = nullptr;  // the same values in MFMA-fragment order (walk_ab_kernel), `frag_groups` 16-channel groups
+    int frag_groups = 0;
     int ldy = 0, cp = 0;
     uint64_t last_use = 0;
+};
+
+struct BasisSlab {  // a piece of the context's cosine-table arena
+    double* dev = nullptr;
+    size_t cap = 0, used = 0;  // doubles
 };
 
 struct EventPair {
@@ -148,11 +158,15 @@ struct dctfp_ctx {
     hipStream_t side = nullptr;
     hipStream_t copy = nullptr;                 // table upload + cosine tables, ahead of the caller's stream
     hipEvent_t ev_tab_free[2] = {}, ev_tab_ready = nullptr;
+    hipEvent_t ev_ws_free = nullptr;            // after the last reader of the Y' scratch (any stream, any call)
     bool tab_busy[2] = {false, false};
+    bool ws_busy = false;
+    std::mutex mu;                              // one host thread at a time inside a context
     int ensure_copy() {
         if (copy) return DCTFP_OK;
         if (hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) { copy = nullptr; g_err = "hipStreamCreate(copy) failed"; return DCTFP_ERR_HIP; }
         if (hipEventCreateWithFlags(&ev_tab_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_ws_free, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_tab_free[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_tab_free[1], hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; return DCTFP_ERR_HIP; }
         return DCTFP_OK;
@@ -160,13 +174,7 @@ struct dctfp_ctx {
     hipEvent_t ev_a[kMaxSlots] = {}, ev_b[kMaxSlots] = {};
     int ensure_side() {
         if (side) return DCTFP_OK;
-#ifdef DCTFP_SIDE_HIGH_PRIO  // A/B switch: stage B's stream at the highest priority
-        int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);
-        hipError_t e = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi);
-#else
         hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
-#endif
         if (e != hipSuccess) { side = nullptr; g_err = std::string("hipStreamCreate: ") + hipGetErrorString(e); return DCTFP_ERR_HIP; }
         for (int i = 0; i < kMaxSlots; ++i) {
             if (hipEventCreateWithFlags(&ev_a[i], hipEventDisableTiming) != hipSuccess ||
@@ -182,8 +190,14 @@ struct dctfp_ctx {
     Staging staging[2];
     int flip = 0;
     DevBuf ws;       // yprime
-    int64_t opt_fuse = 1, opt_pack_y = 1, opt_a_lds_pad = 0, opt_b_variant = 0, opt_a_alt = 0;
+    int64_t opt_fuse = 1, opt_pack_y = 1;
     DevBuf scratch;  // generic idct_quant fs
+    // stage-A cosine tables, one per (domain length, n - 1): filled once, kept for the life of the context
+    std::vector<BasisSlab> basis_slabs;
+    std::unordered_map<uint64_t, double*> basis_tabs;
+    size_t basis_doubles = 0;
+    unsigned long long* degenerate = nullptr;  // device counter: exactly constant channels seen (see dctfp.h)
+    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 8, opt_ab_run_jobs = 0;
     std::map<std::pair<int, int>, StEntry> st_cache;
     uint64_t tick = 0;
     std::vector<EventPair> events;
@@ -193,8 +207,6 @@ struct dctfp_ctx {
 };
 
 namespace {
-
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Records that `stream` has (enqueued) the last reader of table buffer `buf`: a later dctfp_quantize uploads into it
 // from the copy stream only after this point.
@@ -239,6 +251,7 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
             if (i->second.last_use < victim->second.last_use) victim = i;
         HIP_TRY(hipDeviceSynchronize());
         (void)hipFree(victim->second.dev);
+        if (victim->second.frag) (void)hipFree(victim->second.frag);
         ctx->st_cache.erase(victim);
     }
     const int ldy = (int)align_up((size_t)n_cols, 32);
@@ -272,9 +285,73 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
         (void)hipFree(e.dev);
         return fail(DCTFP_ERR_HIP, "hipMemcpy(St): %s", hipGetErrorString(err));
     }
+    if (cp <= 80) {
+        // fragment order for walk_ab_kernel: frag[((q * 4 + r) * NT + c) * 64 + lane] = St[16 q + 4 (lane >> 4) + r][16 c + (lane & 15)]
+        const int nt = cp / 16;
+        e.frag_groups = (n_cols + 15) / 16;
+        std::vector<double> fr((size_t)e.frag_groups * nt * 256, 0.0);
+        for (int q = 0; q < e.frag_groups; ++q)
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < nt; ++c)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int d = 16 * q + 4 * (lane >> 4) + r, col = 16 * c + (lane & 15);
+                        if (d < n_cols) fr[(((size_t)q * 4 + r) * nt + c) * 64 + lane] = host[(size_t)d * cp + col];
+                    }
+        err = hipMalloc((void**)&e.frag, fr.size() * sizeof(double));
+        if (err == hipSuccess) err = hipMemcpy(e.frag, fr.data(), fr.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (err != hipSuccess) {
+            (void)hipFree(e.dev);
+            if (e.frag) (void)hipFree(e.frag);
+            return fail(DCTFP_ERR_HIP, "St fragments: %s", hipGetErrorString(err));
+        }
+    }
     e.last_use = ++ctx->tick;
     auto ins = ctx->st_cache.emplace(key, e);
     *out = &ins.first->second;
+    return DCTFP_OK;
+}
+
+constexpr size_t kBasisSlabDoubles = (size_t)1 << 20;   // 8 MB pieces
+constexpr size_t kBasisCapDoubles = (size_t)1 << 27;    // 1 GiB of tables, then the arena starts over
+
+// Drops every cosine table (only between calls: nothing may be in flight).
+int basis_purge(dctfp_ctx* ctx) {
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto& sl : ctx->basis_slabs) (void)hipFree(sl.dev);
+    ctx->basis_slabs.clear();
+    ctx->basis_tabs.clear();
+    ctx->basis_doubles = 0;
+    return DCTFP_OK;
+}
+
+// Device address of the cosine table of (len, nk); a table seen for the first time is appended to `fresh`
+// (the caller launches basis_kernel for those before anything reads them).
+int basis_lookup(dctfp_ctx* ctx, uint32_t len, int nk, double** out, std::vector<BasisJob>& fresh) {
+    const uint64_t key = ((uint64_t)nk << 32) | len;
+    auto it = ctx->basis_tabs.find(key);
+    if (it != ctx->basis_tabs.end()) {
+        *out = it->second;
+        return DCTFP_OK;
+    }
+    const size_t need = align_up((size_t)len * nk, 2);  // 16-byte granules (s_load_dwordx4)
+    if (ctx->basis_slabs.empty() || ctx->basis_slabs.back().used + need > ctx->basis_slabs.back().cap) {
+        BasisSlab sl;
+        sl.cap = std::max(need, kBasisSlabDoubles);
+        hipError_t e = hipMalloc((void**)&sl.dev, sl.cap * sizeof(double));
+        if (e != hipSuccess) return fail(DCTFP_ERR_NOMEM, "hipMalloc(cosine tables, %zu bytes): %s", sl.cap * sizeof(double), hipGetErrorString(e));
+        ctx->basis_slabs.push_back(sl);
+    }
+    BasisSlab& sl = ctx->basis_slabs.back();
+    double* tab = sl.dev + sl.used;
+    sl.used += need;
+    ctx->basis_doubles += need;
+    ctx->basis_tabs.emplace(key, tab);
+    BasisJob bj;
+    bj.tab = tab;
+    bj.len = len;
+    bj.reserved = 0;
+    fresh.push_back(bj);
+    *out = tab;
     return DCTFP_OK;
 }
 
@@ -296,7 +373,7 @@ struct AParams {
     const Walk* walks;
     bool fused;
     const PieceA* pieces;
-    const double* basis;
+    unsigned long long* degenerate;
     char* yprime;
     int64_t job_bytes;
     int packed;
@@ -305,36 +382,20 @@ struct AParams {
     int ldy;
     int n_slabs;
     unsigned grid;
-    bool alt;          // experimental twin of the kernel (option a_alt)
-    unsigned dyn_lds;  // unused dynamic LDS per workgroup: caps the workgroups per CU (option a_lds_pad)
     hipStream_t stream;
 };
 
 template <typename T, int N, int VEC, int WAVES, int UNROLL>
 void launch_a_impl(const AParams& p) {
     static const InvTab<N> inv = make_inv<N>();
-    // the experimental twin exists for the main configuration only (float32, 16 B per lane, n = 3, 4 rows in flight)
-    if constexpr (__is_same(T, float) && N == 3 && VEC == 4 && UNROLL == 4 && (WAVES == 2 || WAVES == 4 || WAVES == 8)) {
-        if (p.alt) {
-            if (p.fused)
-                hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, true, true>), dim3(p.grid), dim3(WAVES * 64), p.dyn_lds,
-                                   p.stream, p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld,
-                                   p.ldy, p.n_slabs, inv);
-            else
-                hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, false, true>), dim3(p.grid), dim3(WAVES * 64), p.dyn_lds,
-                                   p.stream, p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld,
-                                   p.ldy, p.n_slabs, inv);
-            return;
-        }
-    }
     if (p.fused)
-        hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, true>), dim3(p.grid), dim3(WAVES * 64), p.dyn_lds, p.stream,
-                           p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld, p.ldy, p.n_slabs,
-                           inv);
+        hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, true>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
+                           p.jobs, p.walks, p.pieces, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld, p.ldy, p.n_slabs,
+                           inv, p.degenerate);
     else
-        hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, false>), dim3(p.grid), dim3(WAVES * 64), p.dyn_lds, p.stream,
-                           p.jobs, p.walks, p.pieces, p.basis, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld, p.ldy, p.n_slabs,
-                           inv);
+        hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, false>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
+                           p.jobs, p.walks, p.pieces, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld, p.ldy, p.n_slabs,
+                           inv, p.degenerate);
 }
 
 template <typename T, int N, int VEC>
@@ -386,22 +447,17 @@ void launch_a(const AParams& p, int dtype, int vec, int n, int waves, int unroll
     }
 }
 
-void launch_b_mfma(int variant, int nt, bool packed, unsigned grid, hipStream_t s, const char* yp, int64_t job_bytes, int64_t rows,
+void launch_b_mfma(int nt, bool packed, unsigned grid, hipStream_t s, const char* yp, int64_t job_bytes, int64_t rows,
                    int ldy, const double* st, const JobB* jobs, int n, int m, int8_t* out) {
 #define DCTFP_B_CASE(NT)                                                                                             \
     case NT:                                                                                                         \
         if (packed)                                                                                                  \
-            hipLaunchKernelGGL((stage_b_mfma_kernel<NT, true>), dim3(grid), dim3(DCTFP_B_WG_WAVES * 64), 0, s, yp, job_bytes, rows, ldy, \
+            hipLaunchKernelGGL((stage_b_mfma_kernel<NT, true>), dim3(grid), dim3(kBWaves * 64), 0, s, yp, job_bytes, rows, ldy, \
                                st, jobs, n, m, out);                                                                 \
         else                                                                                                         \
-            hipLaunchKernelGGL((stage_b_mfma_kernel<NT, false>), dim3(grid), dim3(DCTFP_B_WG_WAVES * 64), 0, s, yp, job_bytes, rows,   \
+            hipLaunchKernelGGL((stage_b_mfma_kernel<NT, false>), dim3(grid), dim3(kBWaves * 64), 0, s, yp, job_bytes, rows,   \
                                ldy, st, jobs, n, m, out);                                                            \
         break;
-    if (variant == 1 && nt == 5 && packed) {  // option b_variant (A/B): 32-row LDS stages, 138 VGPRs
-        hipLaunchKernelGGL((stage_b_mfma_kernel<5, true, 32, 2>), dim3(grid), dim3(DCTFP_B_WG_WAVES * 64), 0, s, yp, job_bytes, rows, ldy,
-                           st, jobs, n, m, out);
-        return;
-    }
     switch (nt) {
         DCTFP_B_CASE(1)
         DCTFP_B_CASE(2)
@@ -412,14 +468,60 @@ void launch_b_mfma(int variant, int nt, bool packed, unsigned grid, hipStream_t 
         DCTFP_B_CASE(7)
         default:
             if (packed)
-                hipLaunchKernelGGL((stage_b_mfma_kernel<8, true>), dim3(grid), dim3(DCTFP_B_WG_WAVES * 64), 0, s, yp, job_bytes, rows, ldy,
+                hipLaunchKernelGGL((stage_b_mfma_kernel<8, true>), dim3(grid), dim3(kBWaves * 64), 0, s, yp, job_bytes, rows, ldy,
                                    st, jobs, n, m, out);
             else
-                hipLaunchKernelGGL((stage_b_mfma_kernel<8, false>), dim3(grid), dim3(DCTFP_B_WG_WAVES * 64), 0, s, yp, job_bytes, rows, ldy,
+                hipLaunchKernelGGL((stage_b_mfma_kernel<8, false>), dim3(grid), dim3(kBWaves * 64), 0, s, yp, job_bytes, rows, ldy,
                                    st, jobs, n, m, out);
             break;
     }
 #undef DCTFP_B_CASE
+}
+
+struct WParams {
+    const JobA* jobs;
+    const JobB* jobb;
+    const Walk* walks;
+    const Run* runs;
+    const PieceA* pieces;
+    const double* stf;
+    int8_t* out;
+    int n_cols;
+    int64_t ld;
+    int m;
+    unsigned long long* degenerate;
+    unsigned grid;
+    hipStream_t stream;
+};
+
+template <int S, int G, int NT, int UNROLL>
+void launch_walk_impl(const WParams& p, bool fused) {
+    static const InvTab<3> inv = make_inv<3>();
+    if (fused)
+        hipLaunchKernelGGL((walk_ab_kernel<S, G, NT, UNROLL, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
+                           p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
+    else
+        hipLaunchKernelGGL((walk_ab_kernel<S, G, NT, UNROLL, false>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
+                           p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
+}
+
+template <int S, int G>
+int launch_walk_u(const WParams& p, int unroll, bool fused) {
+    if (unroll == 4) launch_walk_impl<S, G, 5, 4>(p, fused);
+    else launch_walk_impl<S, G, 5, 8>(p, fused);
+    return DCTFP_OK;
+}
+
+// Instantiated shapes: S waves cover up to 256 S channels; G = jobs per flush is bounded by the LDS (2304 B per wave and
+// job: G = 4 leaves room for 17 waves per CU, G = 3 for 23).
+int launch_walk(const WParams& p, int s, int g, int unroll, bool fused) {
+    if (s == 3 && g == 4) return launch_walk_u<3, 4>(p, unroll, fused);
+    if (s == 3 && g == 3) return launch_walk_u<3, 3>(p, unroll, fused);
+    if (s == 5 && g == 4) return launch_walk_u<5, 4>(p, unroll, fused);
+    if (s == 5 && g == 3) return launch_walk_u<5, 3>(p, unroll, fused);
+    if (s == 10 && g == 3) return launch_walk_u<10, 3>(p, unroll, fused);
+    if (s == 10 && g == 2) return launch_walk_u<10, 2>(p, unroll, fused);
+    return fail(DCTFP_ERR_INVALID, "walk kernel: no build for %d waves x %d jobs per flush", s, g);
 }
 
 int prof_begin(dctfp_ctx* ctx, int which, hipStream_t s, EventPair** ep) {
@@ -469,6 +571,12 @@ int dctfp_create(int device, dctfp_ctx** out) {
     dctfp_ctx* ctx = new (std::nothrow) dctfp_ctx();
     if (!ctx) return fail(DCTFP_ERR_NOMEM, "dctfp_create: out of host memory");
     ctx->device = device;
+    hipError_t e = hipMalloc((void**)&ctx->degenerate, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->degenerate, 0, sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(DCTFP_ERR_HIP, "dctfp_create: %s", hipGetErrorString(e));
+    }
     *out = ctx;
     return DCTFP_OK;
 }
@@ -481,7 +589,12 @@ int dctfp_destroy(dctfp_ctx* ctx) {
     for (auto& s : ctx->staging) s.release();
     ctx->ws.release();
     ctx->scratch.release();
-    for (auto& kv : ctx->st_cache) (void)hipFree(kv.second.dev);
+    for (auto& kv : ctx->st_cache) {
+        (void)hipFree(kv.second.dev);
+        if (kv.second.frag) (void)hipFree(kv.second.frag);
+    }
+    for (auto& sl : ctx->basis_slabs) (void)hipFree(sl.dev);
+    if (ctx->degenerate) (void)hipFree(ctx->degenerate);
     for (auto& e : ctx->events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -489,6 +602,7 @@ int dctfp_destroy(dctfp_ctx* ctx) {
     if (ctx->copy) {
         (void)hipStreamDestroy(ctx->copy);
         (void)hipEventDestroy(ctx->ev_tab_ready);
+        (void)hipEventDestroy(ctx->ev_ws_free);
         (void)hipEventDestroy(ctx->ev_tab_free[0]);
         (void)hipEventDestroy(ctx->ev_tab_free[1]);
     }
@@ -505,6 +619,7 @@ int dctfp_destroy(dctfp_ctx* ctx) {
 
 int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(DCTFP_ERR_INVALID, "dctfp_set_option: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     std::string n(name);
     if (n == "stage_b") {
         if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "stage_b must be 0 or 1");
@@ -520,14 +635,23 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         ctx->opt_pack_y = value ? 1 : 0;
     } else if (n == "fuse") {
         ctx->opt_fuse = value ? 1 : 0;
-    } else if (n == "a_alt") {
-        ctx->opt_a_alt = value ? 1 : 0;
-    } else if (n == "b_variant") {
-        if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "b_variant must be 0 or 1");
-        ctx->opt_b_variant = value;
-    } else if (n == "a_lds_pad") {
-        if (value < 0 || value > 32768) return fail(DCTFP_ERR_INVALID, "a_lds_pad must be 0..32768 bytes");
-        ctx->opt_a_lds_pad = value;
+    } else if (n == "path") {
+        if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "path must be 0 (auto), 1 (stage A -> Y' -> stage B) or 2 (walk kernel)");
+        ctx->opt_path = value;
+    } else if (n == "ab_group") {
+        if (value != 0 && (value < 2 || value > 4)) return fail(DCTFP_ERR_INVALID, "ab_group must be 0 (auto) or 2..4 jobs per flush");
+        ctx->opt_ab_group = value;
+    } else if (n == "ab_unroll") {
+        if (value != 4 && value != 8) return fail(DCTFP_ERR_INVALID, "ab_unroll must be 4 or 8");
+        ctx->opt_ab_unroll = value;
+    } else if (n == "ab_run_jobs") {
+        if (value < 0 || value > 4096) return fail(DCTFP_ERR_INVALID, "ab_run_jobs must be 0 (auto) .. 4096");
+        ctx->opt_ab_run_jobs = value;
+    } else if (n == "degenerate_channels") {
+        if (value != 0) return fail(DCTFP_ERR_INVALID, "degenerate_channels can only be reset to 0");
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemset(ctx->degenerate, 0, sizeof(unsigned long long)));
     } else if (n == "overlap") {
         if (value < 1 || value > kMaxSlots) return fail(DCTFP_ERR_INVALID, "overlap must be 1..%d", kMaxSlots);
         ctx->opt_overlap = value;
@@ -544,15 +668,24 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
 
 int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     if (!ctx || !name || !value) return fail(DCTFP_ERR_INVALID, "dctfp_get_option: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     std::string n(name);
     if (n == "stage_b") *value = ctx->opt_stage_b;
     else if (n == "a_waves") *value = ctx->opt_a_waves;
     else if (n == "a_unroll") *value = ctx->opt_a_unroll;
     else if (n == "overlap") *value = ctx->opt_overlap;
+    else if (n == "path") *value = ctx->opt_path;
+    else if (n == "ab_group") *value = ctx->opt_ab_group;
+    else if (n == "ab_unroll") *value = ctx->opt_ab_unroll;
+    else if (n == "ab_run_jobs") *value = ctx->opt_ab_run_jobs;
+    else if (n == "degenerate_channels") {  // synchronises the device
+        unsigned long long v = 0;
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(&v, ctx->degenerate, sizeof v, hipMemcpyDeviceToHost));
+        *value = (int64_t)v;
+    }
     else if (n == "fuse") *value = ctx->opt_fuse;
-    else if (n == "a_lds_pad") *value = ctx->opt_a_lds_pad;
-    else if (n == "b_variant") *value = ctx->opt_b_variant;
-    else if (n == "a_alt") *value = ctx->opt_a_alt;
     else if (n == "pack_y") *value = ctx->opt_pack_y;
     else if (n == "profile") *value = ctx->opt_profile;
     else if (n == "workspace_mb") *value = ctx->opt_ws_mb;
@@ -562,6 +695,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
 
 int dctfp_profile(dctfp_ctx* ctx, double ms[2], int64_t launches[2]) {
     if (!ctx || !ms || !launches) return fail(DCTFP_ERR_INVALID, "dctfp_profile: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     for (size_t i = 0; i < ctx->events_used; ++i) {
         EventPair& e = ctx->events[i];
@@ -585,6 +719,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                    const int64_t* seq_rows, const dctfp_piece* pieces, int64_t n_pieces, int64_t n_domains,
                    int8_t* out, int64_t out_stride, void* stream_v) {
     if (!ctx) return fail(DCTFP_ERR_INVALID, "dctfp_quantize: ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     if (n_layers < 0 || n_seq < 0 || n_pieces < 0 || n_domains < 0)
         return fail(DCTFP_ERR_INVALID, "dctfp_quantize: negative count");
     if (n_layers == 0 || n_domains == 0) return DCTFP_OK;
@@ -698,6 +833,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
     }
 
     // ---- groups of consecutive layers with the same geometry ----------------------
+    if (ctx->basis_doubles > kBasisCapDoubles) {  // the cosine-table arena starts over (nothing of this call uses it yet)
+        int rcp = basis_purge(ctx);
+        if (rcp) return rcp;
+    }
     int32_t l0 = 0;
     while (l0 < n_layers) {
         int32_t l1 = l0 + 1;
@@ -709,19 +848,20 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const int n = g.n_keep, m = g.m_keep, nk = n - 1;
         const int64_t n_jobs = (int64_t)ng * n_domains;
         const size_t esz = dtype_size(g.dtype);
+        const bool trivial = (n == 1 || m == 1);  // single resampled value -> 0/0 -> 0
 
-        // staging layout
+        // staging layout (the run and cosine-table lists are bounded by the job count)
         const size_t off_jobb = 0;
         const size_t off_joba = align_up(off_jobb + (size_t)n_jobs * sizeof(JobB), 16);
         const size_t off_piece = align_up(off_joba + (size_t)n_jobs * sizeof(JobA), 16);
         const size_t off_walk = align_up(off_piece + (size_t)ng * n_pieces * sizeof(PieceA), 16);
-        const size_t off_lens = align_up(off_walk + (size_t)n_jobs * sizeof(Walk), 16);
+        const size_t off_run = align_up(off_walk + (size_t)n_jobs * sizeof(Walk), 16);
+        const size_t off_btab = align_up(off_run + (size_t)n_jobs * sizeof(Run), 16);
+        const size_t max_bytes = align_up(off_btab + (size_t)n_domains * sizeof(BasisJob), 16);
         const int buf = ctx->flip;
         Staging& stg = ctx->staging[buf];
         DevBuf& tab = ctx->tables[buf];
         ctx->flip ^= 1;
-        // unique lengths (at most n_domains)
-        const size_t max_bytes = align_up(off_lens + 2 * (size_t)n_domains * sizeof(uint32_t), 16);
         int rc = stg.ensure(max_bytes);
         if (rc) return rc;
         char* h = (char*)stg.p;
@@ -729,31 +869,26 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         JobA* hja = (JobA*)(h + off_joba);
         PieceA* hpc = (PieceA*)(h + off_piece);
         Walk* hwalk = (Walk*)(h + off_walk);
-        uint32_t* hlens = (uint32_t*)(h + off_lens);
+        Run* hrun = (Run*)(h + off_run);
+        BasisJob* hbt = (BasisJob*)(h + off_btab);
 
-        const bool trivial = (n == 1 || m == 1);  // single resampled value -> 0/0 -> 0
-        // one cosine table per distinct domain length (direct-address lookup: lengths are small)
-        LenTable len_off(max_len_all);
-        std::vector<uint32_t> ulen, uoff;
-        uint64_t basis_doubles = 0;
+        // one cosine table per distinct domain length, from the context's cache
+        std::vector<BasisJob> fresh;
+        std::vector<double*> dom_tab((size_t)n_domains, nullptr);
         if (!trivial) {
+            LenTable seen(max_len_all);  // length -> index of the first domain with it
             for (int64_t d = 0; d < n_domains; ++d) {
-                if (!len_off.has(dom_len[d])) {
-                    if (basis_doubles + (uint64_t)dom_len[d] * nk > 0xffffffffu)
-                        return fail(DCTFP_ERR_LIMIT, "cosine tables of one call exceed 2^32 entries");
-                    len_off.set(dom_len[d], (uint32_t)basis_doubles);
-                    ulen.push_back(dom_len[d]);
-                    uoff.push_back((uint32_t)basis_doubles);
-                    basis_doubles += (uint64_t)dom_len[d] * nk;
+                if (seen.has(dom_len[d])) {
+                    dom_tab[d] = dom_tab[seen[dom_len[d]]];
+                } else {
+                    rc = basis_lookup(ctx, dom_len[d], nk, &dom_tab[d], fresh);
+                    if (rc) return rc;
+                    seen.set(dom_len[d], (uint32_t)d);
                 }
             }
         }
-        const size_t nu = ulen.size();
-        uint32_t* hoffs = hlens + nu;
-        for (size_t i = 0; i < nu; ++i) {
-            hlens[i] = ulen[i];
-            hoffs[i] = uoff[i];
-        }
+        for (size_t i = 0; i < fresh.size(); ++i) hbt[i] = fresh[i];
+
         const int ldy_pre = (int)align_up((size_t)g.n_cols, 32);
         const bool fuse = !trivial && n_groups > 0;
         bool vec_ok = true;
@@ -765,13 +900,13 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 hja[job].piece_begin = (uint32_t)((int64_t)li * n_pieces + dom_first[d]);
                 hja[job].n_pieces = dom_np[d];
                 hja[job].n_rows = dom_len[d];
-                hja[job].basis_off = trivial ? 0u : len_off[dom_len[d]];
                 hja[job].reserved = 0;
-                hja[job].w_basis_off = 0;
+                hja[job].basis = dom_tab[d];
+                hja[job].w_basis = nullptr;
                 hja[job].w_ref = nullptr;
                 if (fuse && grp_end[d] >= 0 && !is_whole[d]) {
                     const int64_t w = grp_end[d];  // the whole-protein domain closes the group
-                    hja[job].w_basis_off = len_off[dom_len[w]];
+                    hja[job].w_basis = dom_tab[w];
                     hja[job].w_ref = ly.seq_data[pieces[dom_first[w]].seq];
                 }
             }
@@ -796,8 +931,59 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         if (((size_t)g.ld * esz) % 16 != 0 || g.n_cols % vec_want != 0) vec_ok = false;
         const int vec = vec_ok ? vec_want : 1;
 
-        // ---- chunk plan.  The float64 scratch is a ring of `slots` regions of `sub` jobs each;
-        // a chunk never splits a fused group (its whole-protein job needs every part's slab).
+        // ---- which kernels.  The walk kernel (stage A + B in one launch, nothing but int8 written) takes the
+        // production shapes: n = 3, 64 < m <= 80 (five 16-column groups), float32 rows read 16 B per lane, 512 <= D <= 2560, no giant domain
+        // (a wave streams all rows of its channels).  Everything else runs stage A -> Y' -> stage B.
+        const bool walk_ok = !trivial && n == 3 && m > 64 && m <= 80 && g.dtype == DCTFP_F32 && vec == 4 && g.n_cols >= 512 &&
+                             g.n_cols <= 2560 && max_len_all <= 8192 && ctx->opt_stage_b == 1;
+        const bool use_walk = walk_ok && ctx->opt_path != 1;
+        if (ctx->opt_path == 2 && !walk_ok)
+            return fail(DCTFP_ERR_INVALID, "option path = 2 (walk kernel) but this call is outside its shapes");
+
+        // walks of ALL jobs (walk kernel) -- the two-kernel path builds its walks per chunk below
+        int64_t n_walks = 0, n_runs = 0;
+        int walk_s = 0, walk_g = 0;
+        if (use_walk) {
+            walk_s = g.n_cols <= 768 ? 3 : (g.n_cols <= 1280 ? 5 : 10);
+            walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : (walk_s == 10 ? 3 : 4);
+            for (int64_t j = 0; j < n_jobs;) {
+                const int64_t d = j % n_domains;
+                Walk& wk = hwalk[n_walks++];
+                wk.job_begin = (uint32_t)j;
+                wk.reserved = 0;
+                if (fuse && grp_end[d] >= 0) {  // d is the first part of a fused group
+                    wk.n_parts = (uint32_t)(grp_end[d] - d);
+                    wk.whole_job = (int32_t)(j + (grp_end[d] - d));
+                    j += grp_end[d] - d + 1;
+                } else {
+                    wk.n_parts = 1;
+                    wk.whole_job = -1;
+                    j += 1;
+                }
+            }
+            // runs: consecutive walks until a run holds `want` jobs (a multiple of the flush group, so that most
+            // flushes are full); fewer jobs per run when the batch is small, to keep every CU busy
+            int64_t want = ctx->opt_ab_run_jobs;
+            if (want == 0) {
+                want = 2 * walk_g;
+                while (want > walk_g && n_jobs / want < 4096) want -= walk_g;
+            }
+            for (int64_t w = 0; w < n_walks;) {
+                Run& rn = hrun[n_runs++];
+                rn.walk_begin = (uint32_t)w;
+                rn.job_begin = hwalk[w].job_begin;
+                uint32_t jobs_in = 0;
+                while (w < n_walks && (jobs_in == 0 || (int64_t)jobs_in < want)) {
+                    jobs_in += hwalk[w].n_parts + (hwalk[w].whole_job >= 0 ? 1u : 0u);
+                    ++w;
+                }
+                rn.n_walks = (uint32_t)(w - rn.walk_begin);
+                rn.n_jobs = jobs_in;
+            }
+        }
+
+        // ---- chunk plan of the two-kernel path.  The float64 scratch is a ring of `slots` regions of `sub` jobs
+        // each; a chunk never splits a fused group (its whole-protein job needs every part's slab).
         struct Chunk { int64_t j0, j1, w0, wn; };
         int64_t avg_rows = 0;  // rows per streamed job (launch-shape heuristic)
         {
@@ -816,7 +1002,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const int n_slabs = (ldy_pre + 64 * vec - 1) / (64 * vec);
         int slots = 1;
         int64_t sub = 1;
-        if (!trivial) {
+        if (!trivial && !use_walk) {
             const int64_t budget_jobs = std::max<int64_t>(1, (int64_t)(((size_t)ctx->opt_ws_mb << 20) / job_bytes));
             if (ctx->opt_overlap > 1 && n_jobs >= 2048 && budget_jobs >= 2048) slots = (int)std::min<int64_t>(ctx->opt_overlap, kMaxSlots);
             int64_t max_group = 1;
@@ -827,8 +1013,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             region = std::min<int64_t>(region, (int64_t)0x7fffffff / n_slabs);
             region = std::max<int64_t>(region, max_group);
             // Chunk boundaries: equal shares (fixed-size cuts would leave a short extra chunk whose stage B runs on its
-            // own at the end); when the scratch budget is the limit, as many equal chunks as needed.  (A half-size
-            // last chunk -- its stage B is the only one no stage A hides -- was measured: no difference.)
+            // own at the end); when the scratch budget is the limit, as many equal chunks as needed.
             int64_t nck = slots;
             if (n_jobs / nck + max_group + 1 > region) nck = (n_jobs + region - 1) / region;
             const double shares = (double)nck;
@@ -875,9 +1060,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             }
         }
 
-        const size_t tab_bytes = align_up(off_lens + 2 * nu * sizeof(uint32_t), 16);
-        const size_t off_basis = align_up(tab_bytes, 256);
-        rc = tab.ensure(off_basis + (size_t)basis_doubles * sizeof(double));
+        const size_t tab_bytes = align_up(off_btab + fresh.size() * sizeof(BasisJob), 16);
+        rc = tab.ensure(tab_bytes);
         if (rc) return rc;
         // The tables go up on the context's copy stream, so the upload of this call overlaps the kernels of
         // the previous one; the copy waits until the last user of this table buffer (two calls ago) is done.
@@ -892,9 +1076,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const JobA* dja = (const JobA*)(dt + off_joba);
         const PieceA* dpc = (const PieceA*)(dt + off_piece);
         const Walk* dwalk = (const Walk*)(dt + off_walk);
-        const uint32_t* dlens = (const uint32_t*)(dt + off_lens);
-        const uint32_t* doffs = dlens + nu;
-        double* dbasis = (double*)(dt + off_basis);
+        const Run* drun = (const Run*)(dt + off_run);
+        const BasisJob* dbt = (const BasisJob*)(dt + off_btab);
 
         if (trivial) {
             HIP_TRY(hipEventRecord(ctx->ev_tab_ready, ctx->copy));
@@ -914,15 +1097,48 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         if (rc) return rc;
         const int ldy = st->ldy;
 
-        {
+        if (!fresh.empty()) {  // cosine tables this context has not seen yet (grid.y is limited to 65535)
             uint32_t max_len = 0;
-            for (size_t i = 0; i < nu; ++i) max_len = std::max(max_len, ulen[i]);
+            for (const BasisJob& bj : fresh) max_len = std::max(max_len, bj.len);
             const unsigned gx = (unsigned)std::min<uint64_t>(((uint64_t)max_len * nk + 255) / 256, 1024);
-            hipLaunchKernelGGL(basis_kernel, dim3(gx, (unsigned)nu), dim3(256), 0, ctx->copy, dlens, doffs, nk, dbasis);
-            HIP_TRY(hipGetLastError());
+            for (size_t b0 = 0; b0 < fresh.size(); b0 += 65535) {
+                const unsigned ny = (unsigned)std::min<size_t>(fresh.size() - b0, 65535);
+                hipLaunchKernelGGL(basis_kernel, dim3(gx, ny), dim3(256), 0, ctx->copy, dbt + b0, nk);
+                HIP_TRY(hipGetLastError());
+            }
         }
         HIP_TRY(hipEventRecord(ctx->ev_tab_ready, ctx->copy));
         HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_ready, 0));
+
+        if (use_walk) {
+            // one launch: stage A + stage B per workgroup, int8 out
+            EventPair* ep = nullptr;
+            rc = prof_begin(ctx, 0, stream, &ep);
+            if (rc) return rc;
+            WParams wp;
+            wp.jobs = dja;
+            wp.jobb = djb;
+            wp.walks = dwalk;
+            wp.runs = drun;
+            wp.pieces = dpc;
+            wp.stf = st->frag;
+            wp.out = out;
+            wp.n_cols = g.n_cols;
+            wp.ld = g.ld;
+            wp.m = m;
+            wp.degenerate = ctx->degenerate;
+            wp.grid = (unsigned)n_runs;
+            wp.stream = stream;
+            rc = launch_walk(wp, walk_s, walk_g, (int)ctx->opt_ab_unroll, fuse);
+            if (rc) return rc;
+            HIP_TRY(hipGetLastError());
+            rc = prof_end(ep, stream);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ctx->ev_tab_free[buf], stream));
+            ctx->tab_busy[buf] = true;
+            l0 = l1;
+            continue;
+        }
 
         // Stage A of chunk c runs on the caller's stream, stage B of it on the context's side
         // stream, so the MFMA-bound stage B of one chunk overlaps the HBM-bound stage A of the next.
@@ -935,6 +1151,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             if (rc) return rc;
         }
         hipStream_t sb = side ? ctx->side : stream;
+        // the scratch is the context's: wait for whatever call used it last, on whatever stream
+        if (ctx->ws_busy) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_ws_free, 0));
 
         int64_t c = 0;
         for (const Chunk& ck : plan) {
@@ -951,7 +1169,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 ap.walks = dwalk + ck.w0;
                 ap.fused = fuse;
                 ap.pieces = dpc;
-                ap.basis = dbasis;
+                ap.degenerate = ctx->degenerate;
                 ap.yprime = yprime;
                 ap.job_bytes = (int64_t)job_bytes;
                 ap.packed = packed ? 1 : 0;
@@ -961,8 +1179,6 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 ap.n_slabs = n_slabs;
                 ap.grid = (unsigned)(ck.wn * n_slabs);
                 ap.stream = stream;
-                ap.dyn_lds = (unsigned)ctx->opt_a_lds_pad;
-                ap.alt = ctx->opt_a_alt != 0;
                 int waves = (int)ctx->opt_a_waves;
                 if (waves == 0) {  // auto: short walks want more, smaller workgroups per CU
                     waves = avg_rows >= 320 ? 8 : (avg_rows >= 160 ? 4 : 2);
@@ -982,7 +1198,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             if (rc) return rc;
             if (ctx->opt_stage_b == 1) {
                 const int64_t rows = jn * n;
-                launch_b_mfma((int)ctx->opt_b_variant, st->cp / 16, packed, (unsigned)((rows + DCTFP_B_WG_WAVES * 16 - 1) / (DCTFP_B_WG_WAVES * 16)), sb, yprime, (int64_t)job_bytes, rows, ldy,
+                launch_b_mfma(st->cp / 16, packed, (unsigned)((rows + kBWaves * 16 - 1) / (kBWaves * 16)), sb, yprime, (int64_t)job_bytes, rows, ldy,
                               st->dev, djb + j0, n, m, out);
             } else {
                 hipLaunchKernelGGL(stage_b_valu_kernel, dim3((unsigned)jn), dim3(256), 0, sb, (const double*)yprime, ldy, g.n_cols,
@@ -998,6 +1214,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             const int64_t used = std::min<int64_t>(c, slots);
             for (int64_t k = 0; k < used; ++k) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_b[k], 0));
         }
+        HIP_TRY(hipEventRecord(ctx->ev_ws_free, stream));  // ... and the scratch is free for the next call after this point
+        ctx->ws_busy = true;
         HIP_TRY(hipEventRecord(ctx->ev_tab_free[buf], stream));  // this table buffer may be overwritten after this point
         ctx->tab_busy[buf] = true;
         l0 = l1;
@@ -1008,6 +1226,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
 int dctfp_idct_quant(dctfp_ctx* ctx, const void* vec, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
                      int32_t num, double* scaled_out, double* coef_out, void* stream_v) {
     if (!ctx || !vec) return fail(DCTFP_ERR_INVALID, "dctfp_idct_quant: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     if (dtype != DCTFP_F32 && dtype != DCTFP_F64) return fail(DCTFP_ERR_INVALID, "dctfp_idct_quant: dtype %d", dtype);
     if (n_rows < 1 || n_cols < 1 || ld < n_cols || num < 1) return fail(DCTFP_ERR_INVALID, "dctfp_idct_quant: bad shape");
     if (num > n_rows) return fail(DCTFP_ERR_SHAPE, "dctfp_idct_quant: num %d > %lld rows", num, (long long)n_rows);
@@ -1032,6 +1251,7 @@ int dctfp_idct_quant(dctfp_ctx* ctx, const void* vec, int32_t dtype, int64_t n_r
 
 int dctfp_scale(dctfp_ctx* ctx, const double* vec, int64_t n, double* out, void* stream_v) {
     if (!ctx || !vec || !out) return fail(DCTFP_ERR_INVALID, "dctfp_scale: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     if (n < 1) return fail(DCTFP_ERR_INVALID, "dctfp_scale: empty vector");
     HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_v, vec, n, out);
@@ -1042,6 +1262,7 @@ int dctfp_scale(dctfp_ctx* ctx, const double* vec, int64_t n, double* out, void*
 int dctfp_gather_rows(dctfp_ctx* ctx, const void* embed, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
                       const dctfp_piece* pieces, int64_t n_pieces, double* out, void* stream_v) {
     if (!ctx || !embed || !pieces || !out) return fail(DCTFP_ERR_INVALID, "dctfp_gather_rows: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     if (dtype != DCTFP_F32 && dtype != DCTFP_F64) return fail(DCTFP_ERR_INVALID, "dctfp_gather_rows: dtype %d", dtype);
     if (n_pieces < 1 || n_pieces > 65535 || n_cols < 1 || ld < n_cols) return fail(DCTFP_ERR_INVALID, "dctfp_gather_rows: bad shape");
     hipStream_t stream = (hipStream_t)stream_v;
@@ -1086,6 +1307,7 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
                        int32_t n_prot, double t, int32_t* out_i, int32_t* out_j, float* out_v,
                        const int64_t* out_offs, int32_t* out_n, void* stream_v) {
     if (!ctx || !maps || !ld || !n_res || !out_i || !out_j || !out_v || !out_offs || !out_n)
+    std::lock_guard<std::mutex> lock(ctx->mu);
         return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: NULL argument");
     if (n_prot < 0) return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: negative count");
     if (n_prot == 0) return DCTFP_OK;
@@ -1125,6 +1347,7 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
 int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, int32_t n_cols, int32_t square,
                  void* stream_v) {
     if (!ctx || (!jobs && n_jobs > 0)) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     if (n_jobs < 0 || (!square && n_cols < 1)) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: bad count");
     if (n_jobs == 0) return DCTFP_OK;
     if (n_jobs > 65535 * 64) return fail(DCTFP_ERR_LIMIT, "dctfp_stitch: too many windows in one call");
@@ -1190,6 +1413,7 @@ int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, i
 int dctfp_l1_matrix(dctfp_ctx* ctx, const int8_t* a, int64_t na, int64_t lda, const int8_t* b, int64_t nb, int64_t ldb,
                     int32_t d, int32_t* out, int64_t ldo, void* stream_v) {
     if (!ctx || !a || !b || !out) return fail(DCTFP_ERR_INVALID, "dctfp_l1_matrix: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     if (na < 0 || nb < 0 || d < 1 || lda < d || ldb < d || ldo < nb) return fail(DCTFP_ERR_INVALID, "dctfp_l1_matrix: bad shape");
     if (na == 0 || nb == 0) return DCTFP_OK;
     if ((na + 63) / 64 > 65535) return fail(DCTFP_ERR_LIMIT, "dctfp_l1_matrix: more than 4M rows per call");
@@ -1206,6 +1430,7 @@ int dctfp_l1_matrix(dctfp_ctx* ctx, const int8_t* a, int64_t na, int64_t lda, co
 int dctfp_block_min(dctfp_ctx* ctx, const int32_t* dist, int64_t ldo, const int64_t* idx_a, int64_t npa,
                     const int64_t* idx_b, int64_t npb, int32_t* out_min, int32_t* out_last, void* stream_v) {
     if (!ctx || !dist || !idx_a || !idx_b || !out_min || !out_last) return fail(DCTFP_ERR_INVALID, "dctfp_block_min: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     if (npa < 0 || npb < 0) return fail(DCTFP_ERR_INVALID, "dctfp_block_min: negative count");
     if (npa == 0 || npb == 0) return DCTFP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1219,6 +1444,7 @@ int dctfp_block_min(dctfp_ctx* ctx, const int32_t* dist, int64_t ldo, const int6
 int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k,
                      int32_t* out_val, int32_t* out_idx, void* stream_v) {
     if (!ctx || !dist || !out_val || !out_idx) return fail(DCTFP_ERR_INVALID, "dctfp_row_select: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     if (n_rows < 0 || n_cols < 1 || ld < n_cols || k < 1 || k > n_cols) return fail(DCTFP_ERR_INVALID, "dctfp_row_select: bad shape");
     if (n_rows == 0) return DCTFP_OK;
     if (n_rows > 0x7fffffff) return fail(DCTFP_ERR_LIMIT, "dctfp_row_select: too many rows");

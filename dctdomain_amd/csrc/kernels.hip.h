@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace dctfp {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -23,6 +25,12 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef unsigned short v8us __attribute__((ext_vector_type(8)));
+
+// Cosine tables are read-only for the kernels and always addressed wave-uniformly: a constant-address-space view lets the
+// compiler fetch them through the scalar cache (s_load_dwordx4) -- a pointer loaded from a job record is otherwise a
+// generic pointer and every cosine becomes a 64-lane vector load.
+typedef const double __attribute__((address_space(4))) * CosTab;
+__device__ inline CosTab cos_tab(const double* p) { return (CosTab)(uintptr_t)p; }
 
 struct bf16_t {  // storage-only bfloat16 (the upper half of a float32)
     unsigned short bits;
@@ -32,9 +40,9 @@ struct JobA {              // one (layer, domain) matrix of stage A
     uint32_t piece_begin;  // first PieceA of this job
     uint32_t n_pieces;
     uint32_t n_rows;       // L_d
-    uint32_t basis_off;    // offset (doubles) of this length's cosine table
-    uint32_t w_basis_off;  // fused groups: cosine table of the whole protein ...
     uint32_t reserved;
+    const double* basis;   // this length's cosine table (context-owned cache, one table per distinct length)
+    const double* w_basis; // fused groups: cosine table of the whole protein ...
     const void* w_ref;     // ... and the whole protein's first row
 };
 
@@ -69,18 +77,22 @@ __device__ inline double cospi_ratio(uint64_t p, uint64_t q) {
 }
 
 // ---------------------------------------------------------------------------
-// K0: cosine tables for stage A.  Table of length L at basis[off .. off + L*NK):
-//     basis[off + t*NK + (k-1)] = cos(pi k (2t+1) / (2L))
+// K0: cosine tables for stage A, one per distinct domain length (filled once per context, then reused by
+// every later call).  Table of length L:   tab[t*NK + (k-1)] = cos(pi k (2t+1) / (2L))
 // ---------------------------------------------------------------------------
-__global__ void basis_kernel(const uint32_t* __restrict__ lens, const uint32_t* __restrict__ offs, int nk,
-                             double* __restrict__ basis) {
-    const uint32_t len = lens[blockIdx.y];
-    const uint32_t off = offs[blockIdx.y];
-    const uint64_t total = (uint64_t)len * nk;
+struct BasisJob {
+    double* tab;
+    uint32_t len;
+    uint32_t reserved;
+};
+
+__global__ void basis_kernel(const BasisJob* __restrict__ tabs, int nk) {
+    const BasisJob tj = tabs[blockIdx.y];
+    const uint64_t total = (uint64_t)tj.len * nk;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t t = i / nk;
         const uint64_t k = i % nk + 1;
-        basis[off + i] = cospi_ratio(k * (2 * t + 1), 2 * (uint64_t)len);
+        tj.tab[i] = cospi_ratio(k * (2 * t + 1), 2 * (uint64_t)tj.len);
     }
 }
 
@@ -110,11 +122,7 @@ template <typename T, int VEC>
 __device__ inline typename Raw<T, VEC>::type load_raw(const T* p) {
     typedef typename Raw<T, VEC>::type R;
     typedef const R __attribute__((address_space(1))) * GP;
-#ifdef DCTFP_PLAIN_LOADS  // A/B switch (tools/ab_build_run.sh): default cache policy instead of nt
-    return *(GP)(uintptr_t)p;
-#else
-    return __builtin_nontemporal_load((GP)(uintptr_t)p);
-#endif
+    return __builtin_nontemporal_load((GP)(uintptr_t)p);  // +6..8 % over the default cache policy (profiles/r01)
 }
 // Element v of a raw image as float64 (every storage type converts exactly).
 template <typename T, int VEC, typename R>
@@ -138,20 +146,22 @@ __device__ inline double raw_elem(const R& r, int v) {
 // kernel streams at 7.0 TB/s for every job length, and issuing the same stores at the start of the workgroup
 // instead of its end changes nothing -- it is the write traffic, not a wait (profiles/r01/stage_a_store_experiments.txt).
 // Written through at agent scope (`sc1`) they cost about half of that; nt and sc0 sc1 measure the same within 1 %.
-template <bool WRITE_BACK = false, typename V>
+template <typename V>
 __device__ inline void store_through(V* p, V v) {
-    if constexpr (WRITE_BACK) *p = v;  // the ordinary store, kept for the A/B twin (option a_alt)
-    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------
-// Stage-A epilogue of one channel: resample the K-1 accumulated coefficients to N points,
-// min-max scale them (scale(): src/fingerprint.py:110-123, applied per channel at :139-140)
-// and store Y'[j][col], j < N.  Padding columns (col >= n_cols) are written as 0.
+// Stage-A epilogue of one channel: resample the K-1 accumulated coefficients to N points and
+// min-max scale them (scale(): src/fingerprint.py:110-123, applied per channel at :139-140).
+// `degenerate` counts the channels whose N resampled values are all equal (an exactly constant
+// channel): 0/0 = NaN here and wherever the reference's FFT cancels exactly, but round-off noise in
+// the reference at the other lengths (tests/golden/fence_golden.json) -- the one input class where the
+// result is reported instead of matched.
 // ---------------------------------------------------------------------------
-template <int N, bool WB = false>
-__device__ inline void finish_channel(const double (&f)[N > 1 ? N - 1 : 1], const InvTab<N>& inv, double* __restrict__ o,
-                                      int ldy, bool pad, bool packed, void* pk) {
+template <int N>
+__device__ inline void scale_channel(const double (&f)[N > 1 ? N - 1 : 1], const InvTab<N>& inv, bool pad, double (&z)[N],
+                                     unsigned long long* __restrict__ degenerate) {
     constexpr int NK = N - 1;
     double y[N];
     double mn = INFINITY, mx = -INFINITY;
@@ -167,42 +177,92 @@ __device__ inline void finish_channel(const double (&f)[N > 1 ? N - 1 : 1], cons
         mx = fmax(mx, s);
     }
     const double den = mx - mn;
+    if (!bad && den == 0.0 && !pad) atomicAdd(degenerate, 1ull);
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[j] = pad ? 0.0 : (bad ? __builtin_nan("") : (y[j] - mn) / den);
+}
+
+// n = 3: the scaled values of a channel are {0, t, 1} (or NaN): one float64 t and a 2-bit state per row
+// (0 -> 0.0, 1 -> 1.0, 2 -> t, 3 -> NaN) carry them exactly: 9 bytes instead of 24.
+__device__ inline void pack_channel(const double (&z)[3], double& t, unsigned& code) {
+    t = 0.0;
+    code = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {  // selects only: this runs per channel with divergent values
+        const bool is_nan = z[j] != z[j], is_zero = z[j] == 0.0, is_one = z[j] == 1.0;
+        const unsigned st = is_nan ? 3u : (is_zero ? 0u : (is_one ? 1u : 2u));
+        t = (st == 2u) ? z[j] : t;
+        code |= st << (2 * j);
+    }
+}
+
+// scale_channel + pack_channel for n = 3 with ONE division instead of three: (y - min) / (max - min) is exactly 0 for the
+// minimum and exactly 1 for the maximum whenever max - min is finite and positive, NaN or 0 by the IEEE rules otherwise;
+// only the middle value needs the divider.  Same states and the same t, bit for bit, as pack_channel(scale_channel()).
+__device__ inline void scale_pack3(const double (&f)[2], const InvTab<3>& inv, bool pad, double& t, unsigned& code,
+                                   unsigned long long* __restrict__ degenerate) {
+    double y[3];
+    double mn = INFINITY, mx = -INFINITY;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double s = fma(inv.c[j * 2 + 1], f[1], fma(inv.c[j * 2], f[0], 0.0));
+        y[j] = s;
+        bad |= (s != s);
+        mn = fmin(mn, s);
+        mx = fmax(mx, s);
+    }
+    const double den = mx - mn;
+    if (!bad && den == 0.0 && !pad) atomicAdd(degenerate, 1ull);
+    const bool zero_ok = den > 0.0;                    // 0 / den = 0   (else 0 / 0 or 0 / NaN = NaN)
+    const bool one_ok = zero_ok && den < INFINITY;     // den / den = 1 (else inf / inf = NaN)
+    const bool den_inf = den == INFINITY;              // finite / inf = 0
+    double mid = 0.0;
+    code = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double num = y[j] - mn;
+        const bool is0 = num == 0.0, is1 = num == den;
+        unsigned st = den_inf ? 0u : 2u;
+        st = is1 ? (one_ok ? 1u : 3u) : st;
+        st = is0 ? (zero_ok ? 0u : 3u) : st;
+        st = (bad || num != num) ? 3u : st;
+        mid = (st == 2u) ? num : mid;
+        code |= st << (2 * j);
+    }
+    t = mid / den;
+    if (pad) {
+        t = 0.0;
+        code = 0;
+    }
+}
+
+// ... and stores Y'[j][col], j < N (two-kernel path).  Padding columns (col >= n_cols) are written as 0.
+template <int N>
+__device__ inline void finish_channel(const double (&f)[N > 1 ? N - 1 : 1], const InvTab<N>& inv, double* __restrict__ o,
+                                      int ldy, bool pad, bool packed, void* pk, unsigned long long* __restrict__ degenerate) {
+    double z[N];
+    scale_channel<N>(f, inv, pad, z, degenerate);
     if constexpr (N == 3) {
         if (packed) {
-            // n = 3: the scaled values of a channel are {0, t, 1} (or NaN); store t once (float64) and a
-            // 2-bit state per row (0 -> 0.0, 1 -> 1.0, 2 -> t, 3 -> NaN): 9 bytes instead of 24.
-            double t = 0.0;
-            unsigned code = 0;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const double z = bad ? __builtin_nan("") : (y[j] - mn) / den;
-                unsigned st = 2;
-                if (z != z) st = 3;
-                else if (z == 0.0) st = 0;
-                else if (z == 1.0) st = 1;
-                else t = z;
-                code |= st << (2 * j);
-            }
-            if (pad) {
-                t = 0.0;
-                code = 0;
-            }
-            store_through<WB>(o, t);
-            store_through<WB>(reinterpret_cast<uint8_t*>(pk), (uint8_t)code);
+            double t;
+            unsigned code;
+            pack_channel(z, t, code);
+            store_through(o, t);
+            store_through(reinterpret_cast<uint8_t*>(pk), (uint8_t)code);
             return;
         }
     }
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        double z = bad ? __builtin_nan("") : (y[j] - mn) / den;
-        if (pad) z = 0.0;
-        store_through<WB>(o + (size_t)j * ldy, z);
-    }
+    for (int j = 0; j < N; ++j) store_through(o + (size_t)j * ldy, z[j]);
 }
 
-// One value of a packed Y' row: state bits -> 0, 1, t or NaN.
+// One value of a packed Y' row: state bits -> 0, 1, t or NaN (bit selects, no branches).
 __device__ inline double unpack_y(unsigned st, double t) {
-    return st == 0 ? 0.0 : (st == 1 ? 1.0 : (st == 2 ? t : __builtin_nan("")));
+    unsigned long long v = (st == 2u) ? (unsigned long long)__double_as_longlong(t) : 0ull;
+    v = (st == 1u) ? 0x3FF0000000000000ull : v;
+    v = (st == 3u) ? 0x7FF8000000000000ull : v;
+    return __longlong_as_double((long long)v);
 }
 
 // ---------------------------------------------------------------------------
@@ -226,14 +286,15 @@ struct Walk {
     uint32_t reserved;
 };
 
-// ALT = twin of the kernel for in-process A/B (option a_alt, tools/overlap_probe.py): here, ordinary write-back stores
-template <typename T, int N, int VEC, int WAVES, int UNROLL, bool FUSED, bool ALT = false>
-__global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restrict__ jobs,
+// (second launch bound = waves per SIMD the register allocation must allow: the fused variant of the main
+//  configuration sits at the 96-VGPR edge -- 5 waves per SIMD -- and is held there)
+template <typename T, int N, int VEC, int WAVES, int UNROLL, bool FUSED>
+__global__ __launch_bounds__(WAVES * 64, (FUSED && N == 3 && VEC == 4 && UNROLL == 4) ? 5 : 1) void stage_a_kernel(const JobA* __restrict__ jobs,
                                                               const Walk* __restrict__ walks,
                                                               const PieceA* __restrict__ pieces,
-                                                              const double* __restrict__ basis,
                                                               char* __restrict__ yprime, int64_t job_bytes, int packed,
-                                                              int n_cols, int64_t ld, int ldy, int n_slabs, InvTab<N> inv) {
+                                                              int n_cols, int64_t ld, int ldy, int n_slabs, InvTab<N> inv,
+                                                              unsigned long long* __restrict__ degenerate) {
     // yprime: per job either N rows of ldy float64, or (packed, N = 3) ldy float64 t values followed by
     // ldy state bytes (finish_channel)
     constexpr int NK = N - 1;
@@ -282,8 +343,8 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
                 f[k] = s;
             }
             char* __restrict__ jb = yprime + (size_t)job_id * job_bytes;
-            finish_channel<N, ALT>(f, inv, reinterpret_cast<double*>(jb) + col, ldy, col >= n_cols, packed != 0,
-                              jb + (size_t)ldy * sizeof(double) + col);
+            finish_channel<N>(f, inv, reinterpret_cast<double*>(jb) + col, ldy, col >= n_cols, packed != 0,
+                              jb + (size_t)ldy * sizeof(double) + col, degenerate);
         }
     };
 
@@ -291,8 +352,8 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
         const uint32_t job_id = wk.job_begin + part;
         const JobA job = jobs[job_id];
         const PieceA* __restrict__ pc = pieces + job.piece_begin;
-        const double* __restrict__ bt = basis + job.basis_off;
-        const double* __restrict__ wt = basis + job.w_basis_off;
+        const CosTab bt = cos_tab(job.basis);
+        const CosTab wt = cos_tab(job.w_basis);
 
         double acc[NK][VEC];
         double ref[VEC];
@@ -309,10 +370,10 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
         for (uint32_t p = 0; p < job.n_pieces; ++p) {
             const PieceA piece = pc[p];
             const T* __restrict__ base = reinterpret_cast<const T*>(piece.ptr) + colc;
-            const double* __restrict__ btp = bt + (size_t)piece.t0 * NK;
-            const double* __restrict__ wtp = wt + (size_t)piece.w0 * NK;
+            const CosTab btp = bt + (size_t)piece.t0 * NK;
+            const CosTab wtp = wt + (size_t)piece.w0 * NK;
             auto row_update = [&](const typename Raw<T, VEC>::type& x, uint32_t r) {
-                const double* __restrict__ c = btp + (size_t)r * NK;
+                const CosTab c = btp + (size_t)r * NK;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     const double d = raw_elem<T, VEC>(x, v) - ref[v];
@@ -320,7 +381,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_a_kernel(const JobA* __restr
                     for (int k = 0; k < NK; ++k) acc[k][v] = fma(c[k], d, acc[k][v]);
                 }
                 if (FUSED && has_w) {
-                    const double* __restrict__ cw = wtp + (size_t)r * NK;
+                    const CosTab cw = wtp + (size_t)r * NK;
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         const double dw = raw_elem<T, VEC>(x, v) - wref[v];
@@ -367,17 +428,13 @@ __device__ inline int8_t quant127(double num, double den, bool bad) {
 //   f64 MFMA layouts (cdna_hip_programming.md section 3): A[i = l&15][k = l>>4],
 //   B[k = l>>4][j = l&15], C/D reg i: row = (l>>4) + 4 i, col = l & 15.
 // ---------------------------------------------------------------------------
-#ifndef DCTFP_B_WG_WAVES
-#define DCTFP_B_WG_WAVES 4  // waves (16-row tiles) per stage-B workgroup (A/B: tools/ab_build_run.sh)
-#endif
-#ifndef DCTFP_B_KB
-#define DCTFP_B_KB 16  // K rows of St per LDS stage
-#endif
+constexpr int kBWaves = 4;  // waves (16-row tiles) per stage-B workgroup
+constexpr int kBKRows = 16;  // K rows of St per LDS stage
 // Register budget as waves per SIMD: up to 5 column tiles (m <= 80, the reference's setting) fit 96 VGPRs with
 // 16-row LDS stages -- the footprint of a fused stage-A wave, so a stage-B wave fits wherever one of those leaves.
 constexpr int stage_b_min_waves(int nt) { return nt <= 5 ? 5 : (nt <= 7 ? 3 : 2); }
-template <int NT, bool PACKED, int KB = DCTFP_B_KB, int MINW = stage_b_min_waves(NT)>
-__global__ __launch_bounds__(DCTFP_B_WG_WAVES * 64, MINW) void stage_b_mfma_kernel(const char* __restrict__ ypb, int64_t job_bytes,
+template <int NT, bool PACKED, int KB = kBKRows, int MINW = stage_b_min_waves(NT)>
+__global__ __launch_bounds__(kBWaves * 64, MINW) void stage_b_mfma_kernel(const char* __restrict__ ypb, int64_t job_bytes,
                                                             int64_t n_rows_total, int ldy, const double* __restrict__ st,
                                                             const JobB* __restrict__ jobs, int n, int m,
                                                             int8_t* __restrict__ out) {
@@ -389,8 +446,8 @@ __global__ __launch_bounds__(DCTFP_B_WG_WAVES * 64, MINW) void stage_b_mfma_kern
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane >> 4, r16 = lane & 15;
-    constexpr int BT = DCTFP_B_WG_WAVES * 64;  // threads per workgroup
-    const int64_t row0 = (int64_t)blockIdx.x * (DCTFP_B_WG_WAVES * 16) + wave * 16;
+    constexpr int BT = kBWaves * 64;  // threads per workgroup
+    const int64_t row0 = (int64_t)blockIdx.x * (kBWaves * 16) + wave * 16;
     int64_t arow = row0 + r16;
     if (arow >= n_rows_total) arow = n_rows_total - 1;
     // A operand source: row (job, j) of Y'.  Plain: float64 row.  PACKED (n = 3): the job's t row + state bytes.
@@ -570,6 +627,287 @@ __global__ __launch_bounds__(256) void stage_b_valu_kernel(const double* __restr
         int8_t* __restrict__ o = out + jobs[job].out_off + (int64_t)j * m;
         const double den = mx - mn;
         for (int c = lane; c < m; c += 64) o[c] = quant127(bl[j * m + c] - mn, den, bad != 0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3: stage A and stage B in ONE kernel ("walk" kernel; n = 3, m <= 80, float32 rows read as 16 B per lane).
+//
+// The two-kernel path sends Y' (9 B per channel and job) through HBM.  That is 0.45 % of the bytes at the headline
+// shape but costs 5 % there and up to 30 % on 25-row domains: writes beside a saturated read stream (DESIGN.md
+// section 4, K1).  Here a workgroup owns ALL channels of its jobs -- wave w streams channels [256 w, 256 w + 256) of
+// every row -- so the scaled channels never leave the CU: they are packed into the wave's own LDS slot, and every
+// G jobs the workgroup contracts the G x 3 rows against the stage-B basis with v_mfma_f64_4x4x4_4b_f64 and
+// writes 240 bytes per job.  What reaches HBM is the int8 result alone.
+//
+//   grid  : one workgroup per run = a few consecutive walks (a walk = one job, or the parts of a protein + the
+//           whole protein fed from the same rows, as in stage_a_kernel); the jobs of a run are consecutive.
+//   block : S = ceil(D / 256) waves, no row split: a wave streams every row of its 256 channels, UNROLL rows in
+//           flight, cosines through the scalar cache.  No barrier per job -- the epilogue of a job is wave-private.
+//   flush : every G jobs (or at the end of the run).  v_mfma_f64_4x4x4_4b_f64 (measured 16.8 cycles, 75 TFLOP/s with
+//           8 independent accumulators; tools/microbench/mfma_f64_probe.hip): per block b = (lane >> 2) & 3
+//               A[i = lane & 3][k = lane >> 4],  B[k = lane >> 4][j = lane & 3],  D[i = lane >> 4][j = lane & 3]
+//           so with the SAME A in the four blocks one instruction multiplies 4 rows (3 used: a job's three resampled
+//           positions) x 4 channels by 4 channels x 16 columns: D lane = Z[row lane >> 4][16 c + (lane & 15)].
+//           Each wave contracts its own 256 channels (K split over the waves); the partial 3 x 80 blocks are summed
+//           through LDS in wave order (deterministic), then per row min / max, scale, x 127, truncate.
+//   stf   : the stage-B basis in fragment order, stf[(((q * 4 + r) * NT + c) * 64 + lane] =
+//           St[16 q + 4 (lane >> 4) + r][16 c + (lane & 15)]  (q = 16-channel group, r = k-step inside it, c = 16-column
+//           group): the B operand of one MFMA is 512 contiguous bytes, the NT operands of a k-step follow each other.
+//           The channel order inside a group (k = 4 (lane >> 4) + r) is the one the packed Y' is read in.
+// ---------------------------------------------------------------------------
+struct Run {
+    uint32_t walk_begin;  // first Walk of this workgroup
+    uint32_t n_walks;
+    uint32_t job_begin;   // first job (the jobs of a run are consecutive)
+    uint32_t n_jobs;
+};
+
+constexpr int kWalkChannels = 256;  // channels per wave: 64 lanes x 4 float32
+
+template <int S, int G, int NT, int UNROLL, bool FUSED>
+__global__ __launch_bounds__(S * 64, 4) void walk_ab_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
+                                                          const Walk* __restrict__ walks, const Run* __restrict__ runs,
+                                                          const PieceA* __restrict__ pieces, const double* __restrict__ stf,
+                                                          int8_t* __restrict__ out, int n_cols, int64_t ld, int m,
+                                                          InvTab<3> inv, unsigned long long* __restrict__ degenerate) {
+    constexpr int VEC = 4, NK = 2;
+    // per wave and slot: 256 t values (later reused for the wave's partial 3 x (NT*16) block) + 256 state bytes
+    __shared__ double lds_t[S][G][kWalkChannels];
+    __shared__ uint32_t lds_c[S][G][kWalkChannels / 4];
+    static_assert(3 * NT * 16 <= kWalkChannels, "partial Z block must fit the slot it reuses");
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const Run run = runs[blockIdx.x];
+    const int col0 = (wave * 64 + lane) * VEC;
+    const bool pad = col0 >= n_cols;
+    const int colc = pad ? 0 : col0;  // out-of-range lanes stream column 0 and are discarded
+    // 16-channel groups of this wave that hold real channels
+    const int n_q = min(16, max(0, (n_cols + 15) / 16 - wave * 16));
+    typedef v4f Rw;
+
+    uint32_t pending = 0;            // jobs whose Y' sits in LDS
+    uint32_t group_job = run.job_begin;  // job of slot 0
+
+    for (uint32_t wi = 0; wi < run.n_walks; ++wi) {
+        const Walk wk = walks[run.walk_begin + wi];
+        const bool has_w = FUSED && wk.whole_job >= 0;
+        const uint32_t n_walk_jobs = wk.n_parts + (has_w ? 1u : 0u);
+        double wacc[FUSED ? NK : 1][VEC];
+        double wref[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            wref[v] = 0.0;
+#pragma unroll
+            for (int k = 0; k < (FUSED ? NK : 1); ++k) wacc[k][v] = 0.0;
+        }
+        if (has_w) {
+            const Rw w0 = load_raw<float, VEC>(reinterpret_cast<const float*>(jobs[wk.job_begin].w_ref) + colc);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) wref[v] = (double)w0[v];
+        }
+
+        for (uint32_t part = 0; part < n_walk_jobs; ++part) {
+            double f[NK][VEC];
+            if (part < wk.n_parts) {
+                // ---- stage A of one job: every row of this wave's 256 channels
+                const JobA job = jobs[wk.job_begin + part];
+                const PieceA* __restrict__ pc = pieces + job.piece_begin;
+                double ref[VEC];
+#pragma unroll
+                for (int k = 0; k < NK; ++k)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) f[k][v] = 0.0;
+                {
+                    const Rw r0 = load_raw<float, VEC>(reinterpret_cast<const float*>(pc[0].ptr) + colc);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) ref[v] = (double)r0[v];
+                }
+                for (uint32_t p = 0; p < job.n_pieces; ++p) {
+                    const PieceA piece = pc[p];
+                    const float* __restrict__ base = reinterpret_cast<const float*>(piece.ptr) + colc;
+                    const CosTab btp = cos_tab(job.basis) + (size_t)piece.t0 * NK;
+                    const CosTab wtp = cos_tab(job.w_basis) + (size_t)piece.w0 * NK;
+                    auto row_update = [&](const Rw& x, uint32_t r) {
+                        const CosTab c = btp + (size_t)r * NK;
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const double d = (double)x[v] - ref[v];
+#pragma unroll
+                            for (int k = 0; k < NK; ++k) f[k][v] = fma(c[k], d, f[k][v]);
+                        }
+                        if (FUSED && has_w) {
+                            const CosTab cw = wtp + (size_t)r * NK;
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) {
+                                const double dw = (double)x[v] - wref[v];
+#pragma unroll
+                                for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(cw[k], dw, wacc[FUSED ? k : 0][v]);
+                            }
+                        }
+                    };
+                    uint32_t r = 0;
+                    for (; r + UNROLL <= piece.n_rows; r += UNROLL) {
+                        Rw xv[UNROLL];
+#pragma unroll
+                        for (int u = 0; u < UNROLL; ++u) xv[u] = load_raw<float, VEC>(base + (size_t)(r + u) * ld);
+#pragma unroll
+                        for (int u = 0; u < UNROLL; ++u) {
+                            row_update(xv[u], r + u);
+                            if constexpr (FUSED) __builtin_amdgcn_sched_barrier(0);  // row by row: the fused variant has no registers for more
+                        }
+                    }
+                    if constexpr (UNROLL > 4) {  // what is left of the piece: a group of 4 ...
+                        if (r + 4 <= piece.n_rows) {
+                            Rw xv[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) xv[u] = load_raw<float, VEC>(base + (size_t)(r + u) * ld);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) row_update(xv[u], r + u);
+                            r += 4;
+                        }
+                    }
+                    if (r < piece.n_rows) {  // ... and the last 1-3 rows, their loads issued together too
+                        Rw xv[3];
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+                            if (r + u < piece.n_rows) xv[u] = load_raw<float, VEC>(base + (size_t)(r + u) * ld);
+#pragma unroll
+                        for (int u = 0; u < 3; ++u)
+                            if (r + u < piece.n_rows) row_update(xv[u], r + u);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NK; ++k)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) f[k][v] = wacc[FUSED ? k : 0][v];
+            }
+
+            // ---- epilogue of the job: scale each of my 4 channels, pack into my slot (wave-private, no barrier)
+            {
+                v4d t4;
+                uint32_t c4 = 0;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const double fk[NK] = {f[0][v], f[1][v]};
+                    double t;
+                    unsigned code;
+                    scale_pack3(fk, inv, pad, t, code, degenerate);
+                    t4[v] = t;
+                    c4 |= code << (8 * v);
+                    __builtin_amdgcn_sched_barrier(0);  // one channel at a time (register pressure)
+                }
+                *reinterpret_cast<v4d*>(&lds_t[wave][pending][VEC * lane]) = t4;
+                lds_c[wave][pending][lane] = c4;
+            }
+            ++pending;
+            const bool last = (wi + 1 == run.n_walks) && (part + 1 == n_walk_jobs);
+            if (pending < (uint32_t)G && !last) continue;
+
+            // ---- flush: stage B of the `pending` jobs in LDS (P = pending as a compile-time count)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            auto contract = [&](auto p_const) {
+                constexpr int P = decltype(p_const)::value;
+                const int g4 = lane >> 4, row = lane & 3;
+                double acc[P][NT];
+#pragma unroll
+                for (int g = 0; g < P; ++g)
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) acc[g][c] = 0.0;
+                // B fragments of k-step (q, r): NT column groups x 8 bytes per lane, fetched one k-step ahead
+                const double* __restrict__ sq = stf + (size_t)wave * 16 * 4 * NT * 64 + lane;
+                auto fetch_b = [&](double (&b)[NT], int step) {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) b[c] = sq[((size_t)step * NT + c) * 64];
+                };
+                constexpr bool AHEAD = !FUSED;  // the fused variant has no registers to spare for a second operand set
+                double bq[AHEAD ? 2 : 1][NT];
+                if (AHEAD && n_q > 0) fetch_b(bq[0], 0);
+                for (int q = 0; q < n_q; ++q) {
+                    uint32_t c4[P];
+#pragma unroll
+                    for (int g = 0; g < P; ++g) c4[g] = lds_c[wave][g][4 * q + g4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int step = 4 * q + r;
+                        if constexpr (AHEAD) {
+                            if (step + 1 < 4 * n_q) fetch_b(bq[(r + 1) & 1], step + 1);
+                        } else {
+                            fetch_b(bq[0], step);
+                        }
+                        double a[P];
+#pragma unroll
+                        for (int g = 0; g < P; ++g)
+                            a[g] = unpack_y((c4[g] >> (8 * r + 2 * row)) & 3u, lds_t[wave][g][16 * q + 4 * g4 + r]);
+                        // NT * P independent accumulators between two uses of one
+#pragma unroll
+                        for (int c = 0; c < NT; ++c)
+#pragma unroll
+                            for (int g = 0; g < P; ++g)
+                                acc[g][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g], bq[AHEAD ? (r & 1) : 0][c], acc[g][c], 0, 0, 0);
+                    }
+                }
+                // partial blocks -> my slots (the Y' in them is consumed): zp[row][col], rows 0..2 = lanes 0..47
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 48) {
+#pragma unroll
+                    for (int g = 0; g < P; ++g)
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) lds_t[wave][g][(lane >> 4) * (NT * 16) + c * 16 + (lane & 15)] = acc[g][c];
+                }
+            };
+            static_assert(G >= 1 && G <= 4, "flush dispatch covers 1..4 jobs");
+            switch (pending) {
+                case 1: contract(std::integral_constant<int, 1>{}); break;
+                case 2: if constexpr (G >= 2) contract(std::integral_constant<int, 2>{}); break;
+                case 3: if constexpr (G >= 3) contract(std::integral_constant<int, 3>{}); break;
+                default: if constexpr (G >= 4) contract(std::integral_constant<int, 4>{}); break;
+            }
+            __syncthreads();
+            // sum over the waves in wave order, per-row min-max scale, int8 (src/fingerprint.py:193-195)
+            for (uint32_t idx = (uint32_t)wave; idx < pending * 3u; idx += S) {
+                const uint32_t g = idx / 3u, j = idx - 3u * g;
+                double v[2];
+                bool valid[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int col = lane + 64 * h;
+                    valid[h] = col < m;
+                    double sum = 0.0;
+                    if (valid[h]) {
+#pragma unroll
+                        for (int w = 0; w < S; ++w) sum += lds_t[w][g][j * (NT * 16) + col];
+                    }
+                    v[h] = sum;
+                }
+                double mn = INFINITY, mx = -INFINITY;
+                int bad = 0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (valid[h]) {
+                        bad |= (v[h] != v[h]) ? 1 : 0;
+                        mn = fmin(mn, v[h]);
+                        mx = fmax(mx, v[h]);
+                    }
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) {
+                    mn = fmin(mn, __shfl_xor(mn, sft));
+                    mx = fmax(mx, __shfl_xor(mx, sft));
+                    bad |= __shfl_xor(bad, sft);
+                }
+                int8_t* __restrict__ o = out + jobb[group_job + g].out_off + (int64_t)j * m;
+                const double den = mx - mn;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (valid[h]) o[lane + 64 * h] = quant127(v[h] - mn, den, bad != 0);
+            }
+            __syncthreads();  // the slots are free again
+            group_job += pending;
+            pending = 0;
+        }
     }
 }
 

@@ -22,7 +22,7 @@ IDS = [c['id'] for c in CASES]
 
 
 def build_map(case):
-    kw = {k: v for k, v in case['kw'].items() if k != 'pipeline'}
+    kw = {k: v for k, v in case['kw'].items() if k not in ('pipeline', 'pipeline_D')}
     cmap = make_contacts(case['recipe'], case['L'], case['seed'], **kw)
     assert sha256_of(cmap) == case['map_sha256']
     return cmap

@@ -18,7 +18,7 @@ def find(sub, pat):
 
 def short(name):
     name = name.split('(')[0]
-    for key in ('stage_a_kernel', 'stage_b_mfma_kernel', 'stage_b_valu_kernel', 'basis_kernel'):
+    for key in ('walk_ab_kernel', 'stage_a_kernel', 'stage_b_mfma_kernel', 'stage_b_valu_kernel', 'basis_kernel'):
         if key in name:
             return key
     return name[-60:]
@@ -36,7 +36,7 @@ for f in find('trace', '*kernel_stats.csv'):
     print()
 
 counters = defaultdict(lambda: defaultdict(list))
-for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
+for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_sq2'):
     for f in find(sub, '*counter_collection.csv'):
         with open(f) as fh:
             for r in csv.DictReader(fh):
@@ -52,14 +52,15 @@ if counters:
             print(f'| {k} | {c} | {len(vals)} | {m:.6g} |')
             res.setdefault(k, {})[c] = m
     print()
-    if 'stage_a_kernel' in res and 'FETCH_SIZE' in res['stage_a_kernel']:
-        a = res['stage_a_kernel']
+    main = 'walk_ab_kernel' if 'walk_ab_kernel' in res else 'stage_a_kernel'
+    if main in res and 'FETCH_SIZE' in res[main]:
+        a = res[main]
         # MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
         # reads exactly 1/2 of a wide coalesced stream's bytes -> double it; WRITE_SIZE is exact.
         fetch = 2.0 * a['FETCH_SIZE'] * 1024.0
         write = a.get('WRITE_SIZE', 0.0) * 1024.0
-        print('## stage A HBM traffic per launch (gfx950 correction: 2 x FETCH_SIZE KiB + WRITE_SIZE KiB)\n')
+        print(f'## {main} HBM traffic per launch (gfx950 correction: 2 x FETCH_SIZE KiB + WRITE_SIZE KiB)\n')
         print(f'- fetch {fetch / 1e9:.3f} GB, write {write / 1e9:.3f} GB, total {(fetch + write) / 1e9:.3f} GB')
         with open(os.path.join(out, 'traffic.json'), 'w') as fh:
-            json.dump({'stage_a_hbm_bytes_per_launch': fetch + write, 'fetch_bytes': fetch, 'write_bytes': write,
+            json.dump({'kernel': main, 'stage_a_hbm_bytes_per_launch': fetch + write, 'fetch_bytes': fetch, 'write_bytes': write,
                        'raw': a}, fh, indent=1)
