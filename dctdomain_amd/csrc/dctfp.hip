@@ -197,7 +197,7 @@ struct dctfp_ctx {
     std::unordered_map<uint64_t, double*> basis_tabs;
     size_t basis_doubles = 0;
     unsigned long long* degenerate = nullptr;  // device counter: exactly constant channels seen (see dctfp.h)
-    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 8, opt_ab_run_jobs = 0;
+    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0;
     std::map<std::pair<int, int>, StEntry> st_cache;
     uint64_t tick = 0;
     std::vector<EventPair> events;
@@ -636,13 +636,13 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "fuse") {
         ctx->opt_fuse = value ? 1 : 0;
     } else if (n == "path") {
-        if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "path must be 0 (auto), 1 (stage A -> Y' -> stage B) or 2 (walk kernel)");
+        if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "path must be 0 (auto), 1 (stage A -> Y' -> stage B) or 2 (walk kernel wherever its shapes allow)");
         ctx->opt_path = value;
     } else if (n == "ab_group") {
         if (value != 0 && (value < 2 || value > 4)) return fail(DCTFP_ERR_INVALID, "ab_group must be 0 (auto) or 2..4 jobs per flush");
         ctx->opt_ab_group = value;
     } else if (n == "ab_unroll") {
-        if (value != 4 && value != 8) return fail(DCTFP_ERR_INVALID, "ab_unroll must be 4 or 8");
+        if (value != 0 && value != 4 && value != 8) return fail(DCTFP_ERR_INVALID, "ab_unroll must be 0 (auto), 4 or 8");
         ctx->opt_ab_unroll = value;
     } else if (n == "ab_run_jobs") {
         if (value < 0 || value > 4096) return fail(DCTFP_ERR_INVALID, "ab_run_jobs must be 0 (auto) .. 4096");
@@ -936,16 +936,17 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         // (a wave streams all rows of its channels).  Everything else runs stage A -> Y' -> stage B.
         const bool walk_ok = !trivial && n == 3 && m > 64 && m <= 80 && g.dtype == DCTFP_F32 && vec == 4 && g.n_cols >= 512 &&
                              g.n_cols <= 2560 && max_len_all <= 8192 && ctx->opt_stage_b == 1;
-        const bool use_walk = walk_ok && ctx->opt_path != 1;
-        if (ctx->opt_path == 2 && !walk_ok)
-            return fail(DCTFP_ERR_INVALID, "option path = 2 (walk kernel) but this call is outside its shapes");
-
+        // Measured (profiles/r02): the walk kernel wins at D <= 1280 (3 or 5 waves per workgroup); at D = 2560 its 10-wave
+        // workgroups leave one workgroup per CU and the two-kernel path is 4 % faster -- "auto" keeps that one there.
+        const bool use_walk = walk_ok && (ctx->opt_path == 2 || (ctx->opt_path == 0 && g.n_cols <= 1280));
         // walks of ALL jobs (walk kernel) -- the two-kernel path builds its walks per chunk below
         int64_t n_walks = 0, n_runs = 0;
         int walk_s = 0, walk_g = 0;
         if (use_walk) {
             walk_s = g.n_cols <= 768 ? 3 : (g.n_cols <= 1280 ? 5 : 10);
-            walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : (walk_s == 10 ? 3 : 4);
+            // jobs per flush: 4 leaves LDS for 17 waves per CU; fused walks keep two more accumulator sets alive across a
+            // flush and only fit their registers with 3 (and 4 rows in flight instead of 8)
+            walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : ((walk_s == 10 || fuse) ? 3 : 4);
             for (int64_t j = 0; j < n_jobs;) {
                 const int64_t d = j % n_domains;
                 Walk& wk = hwalk[n_walks++];
@@ -1129,7 +1130,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             wp.degenerate = ctx->degenerate;
             wp.grid = (unsigned)n_runs;
             wp.stream = stream;
-            rc = launch_walk(wp, walk_s, walk_g, (int)ctx->opt_ab_unroll, fuse);
+            rc = launch_walk(wp, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : (fuse ? 4 : 8), fuse);
             if (rc) return rc;
             HIP_TRY(hipGetLastError());
             rc = prof_end(ep, stream);

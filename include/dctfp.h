@@ -177,21 +177,28 @@ int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_
                      int32_t* out_val, int32_t* out_idx, void* stream);
 
 /* Tuning / instrumentation knobs (no reference counterpart).
- *   "stage_b"      0 = plain VALU kernel, 1 = MFMA f64 kernel (default)
- *   "a_waves"      waves per workgroup of the stage-A kernel: 0 = by average rows per job (default), 2, 4, 8, 16
- *   "a_unroll"     rows in flight per wave (4 or 8)
- *   "overlap"      sub-chunks of a large batch whose stage B runs on a side stream under the
+ *   "path"         0 (default) = by shape: the walk kernel (stage A + stage B in one launch, nothing but int8 written)
+ *                  for n = 3, 64 < m <= 80, float32 rows, 512 <= D <= 1280; stage A -> scratch -> stage B otherwise;
+ *                  1 = always the two-kernel path; 2 = the walk kernel wherever its shapes allow (also D <= 2560)
+ *   "ab_group"     walk kernel: jobs per stage-B flush (0 = by shape, 2..4)
+ *   "ab_unroll"    walk kernel: rows in flight per wave (0 = by shape, 4, 8)
+ *   "ab_run_jobs"  walk kernel: jobs per workgroup (0 = by batch size)
+ *   "stage_b"      two-kernel path: 0 = plain VALU stage B, 1 = MFMA f64 kernel (default)
+ *   "a_waves"      two-kernel path: waves per stage-A workgroup: 0 = by average rows per job (default), 2, 4, 8, 16
+ *   "a_unroll"     two-kernel path: rows in flight per wave (4 or 8)
+ *   "overlap"      two-kernel path: sub-chunks of a large batch whose stage B runs on a side stream under the
  *                  next sub-chunk's stage A (1 = off, default 4)
- *   "pack_y"       1 (default) = n = 3: the scratch between the kernels holds {0, t, 1} as one float64 + 2-bit
- *                  states per channel (9 bytes instead of 24)
+ *   "pack_y"       two-kernel path, 1 (default) = n = 3: the scratch between the kernels holds {0, t, 1} as one
+ *                  float64 + 2-bit states per channel (9 bytes instead of 24)
  *   "fuse"         1 (default) = proteins given as parts + whole protein are streamed once
- *   "b_variant"    0 (default) = stage B with 16-row LDS stages inside 96 VGPRs; 1 = 32-row stages, 138 VGPRs (m <= 80)
- *   "a_alt"        1 = launch the A/B twin of the stage-A kernel (float32, 16 B per lane, n = 3): ordinary write-back
- *                  stores of Y' instead of write-through ones (measurement knob, same results)
- *   "a_lds_pad"    bytes of unused LDS added to every stage-A workgroup (0 = none): caps the stage-A workgroups
- *                  per CU so that a stage-B workgroup always finds room beside them (measurement knob)
  *   "profile"      1 = bracket the kernels with hipEvents (see dctfp_profile)
- *   "workspace_mb" cap of the float64 scratch between the kernels */
+ *   "workspace_mb" two-kernel path: cap of the float64 scratch between the kernels
+ *   "degenerate_channels"  read: number of (layer, domain, channel) triples seen so far whose resampled values were all
+ *                  equal -- an exactly constant channel.  Mathematically that is 0/0 = NaN and the whole (layer, domain)
+ *                  block becomes 0, which is what this library writes; the reference (scipy / pocketfft) does the same at
+ *                  most domain lengths but scales its own round-off noise at the others (tests/golden/fence_golden.json:
+ *                  225 of the lengths 3..2000), so for these blocks -- and only these -- the result is reported instead of
+ *                  matched.  Reading synchronises the device; writing 0 resets the counter. */
 int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value);
 int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value);
 
