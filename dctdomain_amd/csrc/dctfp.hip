@@ -159,6 +159,9 @@ struct dctfp_ctx {
     hipStream_t copy = nullptr;                 // table upload + cosine tables, ahead of the caller's stream
     hipEvent_t ev_tab_free[2] = {}, ev_tab_ready = nullptr;
     hipEvent_t ev_ws_free = nullptr;            // after the last reader of the Y' scratch (any stream, any call)
+    hipEvent_t ev_basis = nullptr;              // after the last basis_kernel (cosine tables are shared by all later calls)
+    hipStream_t basis_stream = nullptr;
+    bool basis_valid = false;
     bool tab_busy[2] = {false, false};
     bool ws_busy = false;
     std::mutex mu;                              // one host thread at a time inside a context
@@ -167,6 +170,7 @@ struct dctfp_ctx {
         if (hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) { copy = nullptr; g_err = "hipStreamCreate(copy) failed"; return DCTFP_ERR_HIP; }
         if (hipEventCreateWithFlags(&ev_tab_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_ws_free, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_basis, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_tab_free[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_tab_free[1], hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; return DCTFP_ERR_HIP; }
         return DCTFP_OK;
@@ -321,6 +325,7 @@ int basis_purge(dctfp_ctx* ctx) {
     ctx->basis_slabs.clear();
     ctx->basis_tabs.clear();
     ctx->basis_doubles = 0;
+    ctx->basis_valid = false;
     return DCTFP_OK;
 }
 
@@ -603,6 +608,7 @@ int dctfp_destroy(dctfp_ctx* ctx) {
         (void)hipStreamDestroy(ctx->copy);
         (void)hipEventDestroy(ctx->ev_tab_ready);
         (void)hipEventDestroy(ctx->ev_ws_free);
+        (void)hipEventDestroy(ctx->ev_basis);
         (void)hipEventDestroy(ctx->ev_tab_free[0]);
         (void)hipEventDestroy(ctx->ev_tab_free[1]);
     }
@@ -938,7 +944,9 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                              g.n_cols <= 2560 && max_len_all <= 8192 && ctx->opt_stage_b == 1;
         // Measured (profiles/r02): the walk kernel wins at D <= 1280 (3 or 5 waves per workgroup); at D = 2560 its 10-wave
         // workgroups leave one workgroup per CU and the two-kernel path is 4 % faster -- "auto" keeps that one there.
-        const bool use_walk = walk_ok && (ctx->opt_path == 2 || (ctx->opt_path == 0 && g.n_cols <= 1280));
+        // A small call (a protein at a time, the reference's calling pattern) is latency-bound: there the two-kernel path,
+        // which spreads one job over slabs x 8 waves, finishes first.
+        const bool use_walk = walk_ok && (ctx->opt_path == 2 || (ctx->opt_path == 0 && g.n_cols <= 1280 && n_jobs >= 512));
         // walks of ALL jobs (walk kernel) -- the two-kernel path builds its walks per chunk below
         int64_t n_walks = 0, n_runs = 0;
         int walk_s = 0, walk_g = 0;
@@ -1068,9 +1076,13 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         // the previous one; the copy waits until the last user of this table buffer (two calls ago) is done.
         rc = ctx->ensure_copy();
         if (rc) return rc;
-        if (ctx->tab_busy[buf]) HIP_TRY(hipStreamWaitEvent(ctx->copy, ctx->ev_tab_free[buf], 0));
-        HIP_TRY(hipMemcpyAsync(tab.p, stg.p, tab_bytes, hipMemcpyHostToDevice, ctx->copy));
-        HIP_TRY(hipEventRecord(stg.ev, ctx->copy));
+        // (a small call keeps everything on the caller's stream: the hop through the copy stream costs two event waits,
+        //  more than the upload itself)
+        const bool inline_tables = tab_bytes <= (64u << 10) && n_jobs < 512;
+        hipStream_t ts = inline_tables ? stream : ctx->copy;
+        if (ctx->tab_busy[buf]) HIP_TRY(hipStreamWaitEvent(ts, ctx->ev_tab_free[buf], 0));
+        HIP_TRY(hipMemcpyAsync(tab.p, stg.p, tab_bytes, hipMemcpyHostToDevice, ts));
+        HIP_TRY(hipEventRecord(stg.ev, ts));
         stg.pending = true;
         char* dt = (char*)tab.p;
         const JobB* djb = (const JobB*)(dt + off_jobb);
@@ -1081,8 +1093,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const BasisJob* dbt = (const BasisJob*)(dt + off_btab);
 
         if (trivial) {
-            HIP_TRY(hipEventRecord(ctx->ev_tab_ready, ctx->copy));
-            HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_ready, 0));
+            if (!inline_tables) {
+                HIP_TRY(hipEventRecord(ctx->ev_tab_ready, ctx->copy));
+                HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_ready, 0));
+            }
             const int64_t total = n_jobs * n * m;
             const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
             hipLaunchKernelGGL(fill_zero_kernel, dim3(grid), dim3(256), 0, stream, djb, n_jobs, n * m, out);
@@ -1104,12 +1118,21 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             const unsigned gx = (unsigned)std::min<uint64_t>(((uint64_t)max_len * nk + 255) / 256, 1024);
             for (size_t b0 = 0; b0 < fresh.size(); b0 += 65535) {
                 const unsigned ny = (unsigned)std::min<size_t>(fresh.size() - b0, 65535);
-                hipLaunchKernelGGL(basis_kernel, dim3(gx, ny), dim3(256), 0, ctx->copy, dbt + b0, nk);
+                hipLaunchKernelGGL(basis_kernel, dim3(gx, ny), dim3(256), 0, ts, dbt + b0, nk);
                 HIP_TRY(hipGetLastError());
             }
         }
-        HIP_TRY(hipEventRecord(ctx->ev_tab_ready, ctx->copy));
-        HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_ready, 0));
+        if (!fresh.empty()) {
+            HIP_TRY(hipEventRecord(ctx->ev_basis, ts));
+            ctx->basis_stream = ts;
+            ctx->basis_valid = true;
+        }
+        if (!inline_tables) {
+            HIP_TRY(hipEventRecord(ctx->ev_tab_ready, ctx->copy));
+            HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_ready, 0));
+        }
+        // tables cached by an earlier call may have been filled on another stream
+        if (ctx->basis_valid && ctx->basis_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_basis, 0));
 
         if (use_walk) {
             // one launch: stage A + stage B per workgroup, int8 out

@@ -63,7 +63,7 @@ def _npy_vector(blob: bytes) -> np.ndarray:
     for (descr, shape), head in _NPY_HEADERS.items():
         if len(blob) == len(head) + int(np.prod(shape)) * np.dtype(descr).itemsize and blob.startswith(head):
             return np.frombuffer(blob, dtype=descr, offset=len(head)).reshape(shape)
-    vec = np.load(BytesIO(blob), allow_pickle=True)
+    vec = np.load(BytesIO(blob), allow_pickle=False)     # int8 vectors only: a crafted .db must not reach the unpickler
     if vec.ndim == 1 and vec.flags.c_contiguous:
         _NPY_HEADERS.setdefault((vec.dtype.str, vec.shape), blob[:len(blob) - vec.nbytes])
     return vec
@@ -221,7 +221,7 @@ class Database:
 
     def load_fprints(self, pid: str = '') -> list:
         found = self.cur.execute('SELECT vid, fingerprint FROM fingerprints WHERE pid = ?', (pid,))
-        return [(vid, _npy_vector(blob)) for vid, blob in found]
+        return [(vid, _npy_vector(blob).copy()) for vid, blob in found]      # writable, like the reference's np.load
 
     def rename_vid(self):
         """vids 1..N in table order (:268-282), set-based: rows move to -1..-N first so that the

@@ -22,7 +22,7 @@ import time
 
 import numpy as np
 
-from .similarity import block_min, l1_matrix
+from .similarity import block_min, l1_matrix, to_device_int8
 
 L1_FULL_SCALE = 17000      # src/dct-sim.py:24
 HEADER = '#prot1 prot2 sim-domain sim-global'
@@ -78,7 +78,23 @@ class Blocks:
         a = np.load(file_a)
         b = a if file_b is None else np.load(file_b)
         self.rows, self.cols = a['sid'], b['sid']
-        self.mn, self.last = block_min(l1_matrix(a['dct'], b['dct']), a['idx'], b['idx'])
+        # protein stripes of `a`: the int32 distance matrix of a stripe stays within ~1 GiB (the protein x protein result
+        # is what is kept; the reference loops pair by pair, src/dct-sim.py:126-176)
+        da, ia = a['dct'], np.asarray(a['idx'], dtype=np.int64)
+        db_dev = to_device_int8(b['dct'])
+        budget = max(1, (1 << 28) // max(1, db_dev.shape[0]))
+        mns, lasts, p0 = [], [], 0
+        while p0 < len(ia) - 1:
+            p1 = p0 + 1
+            while p1 < len(ia) - 1 and ia[p1 + 1] - ia[p0] <= budget:
+                p1 += 1
+            mn_t, last_t = block_min(l1_matrix(da[ia[p0]:ia[p1]], db_dev), ia[p0:p1 + 1] - ia[p0], b['idx'])
+            mns.append(mn_t)
+            lasts.append(last_t)
+            p0 = p1
+        nb = len(b['idx']) - 1
+        self.mn = np.concatenate(mns) if mns else np.zeros((0, nb), np.int32)
+        self.last = np.concatenate(lasts) if lasts else np.zeros((0, nb), np.int32)
 
     def scores(self, i: int, j: int) -> tuple:
         return _scores(self.mn[i, j], self.last[i, j])

@@ -167,7 +167,12 @@ class Fingerprint:
         ``i`` (dict order).  Afterwards ``quants[dom]`` is an integer array of
         ``sum n_i*m_i`` values 0..127 and ``domains == list(quants)``.  Raises
         ``ValueError`` where the reference's reshape does (a domain shorter than n, a layer
-        narrower than m) -- before touching ``quants``."""
+        narrower than m) -- before touching ``quants``.
+
+        One protein per call is the reference's calling pattern, not the fast one: a call costs a
+        table upload, one or two kernel launches and a device -> host copy of 480 bytes per domain
+        (about 60 us in all).  ``make_db.fingerprint_batch`` / ``batch.quantize_batch`` take many
+        proteins per call and are the throughput path."""
         embeds = list(self.embed.values())
         if len(qdim) < 2 * len(embeds):
             raise IndexError('list index out of range')      # qdim[i*2] in the reference
@@ -178,8 +183,9 @@ class Fingerprint:
                 break
         mats = [_to_device_matrix(e, device, keep_half=True) for e in embeds]
 
-        # layers are grouped while they share the row count (one piece table per group)
-        results = []          # per layer: (table, tensor rows, column offset, n*m)
+        # layers are grouped while they share the row count (one piece table per group); every group is
+        # enqueued first, the results come back in ONE pinned copy and one synchronisation
+        groups = []           # (table, device int8 tensor, first layer, last layer)
         i = 0
         while i < len(mats):
             j = i
@@ -187,25 +193,79 @@ class Fingerprint:
                     and mats[j + 1].device == mats[i].device:
                 j += 1
             table = PieceTable([mats[i].shape[0]], [self.domains])
-            layers = [LayerBatch([mats[k]], qdim[2 * k], qdim[2 * k + 1]) for k in range(i, j + 1)]
-            out = quantize_batch(layers, table)
-            host = out.cpu().numpy() if table.n_domains else np.zeros((0, 0), np.int8)
-            off = 0
-            for k in range(i, j + 1):
-                nm = qdim[2 * k] * qdim[2 * k + 1]
-                results.append((table, host, off, nm))
-                off += nm
+            if table.n_domains:
+                layers = [LayerBatch([mats[k]], qdim[2 * k], qdim[2 * k + 1]) for k in range(i, j + 1)]
+                width = sum(l.n_keep * l.m_keep for l in layers)
+                out = _result_buffer(mats[i].device, table.n_domains, width)
+                quantize_batch(layers, table, out=out)
+                groups.append((table, out, i, j))
             i = j + 1
+        hosts = _fetch_results([g[1] for g in groups])
 
-        for table, host, off, nm in results:                   # layer-major, then domain order
-            for row, key in enumerate(table.keys):
-                self.quants.setdefault(key, [])
-                if not isinstance(self.quants[key], list):
-                    self.quants[key] = list(self.quants[key])
-                self.quants[key].extend(host[row, off:off + nm].astype(np.int64).tolist())
+        # quants[key] = the blocks of every layer, layer-major, then domain order (:184-196); a key that occurs
+        # twice (two domain strings cleaned to the same key) is extended twice, as there
+        pieces = {}
         for key, value in self.quants.items():
-            self.quants[key] = np.array(value)
+            pieces[key] = [np.asarray(value)]
+        for (table, _, first, last), host in zip(groups, hosts):
+            off = 0
+            for k in range(first, last + 1):
+                nm = qdim[2 * k] * qdim[2 * k + 1]
+                for row, key in enumerate(table.keys):
+                    pieces.setdefault(key, []).append(host[row, off:off + nm])
+                off += nm
+        for key, parts in pieces.items():
+            self.quants[key] = np.concatenate(parts).astype(np.int64) if len(parts) > 1 or parts[0].dtype != np.int64 \
+                else parts[0]
         self.domains = list(self.quants.keys())
+
+
+# per-device scratch of the one-protein-per-call path: an int8 result buffer on the GPU and its pinned twin
+_RESULTS = {}
+
+
+def _result_buffer(device, n_rows: int, width: int) -> torch.Tensor:
+    """A (n_rows, width) int8 view of a reusable device buffer -- no allocation per call.  Several views may be
+    handed out between two ``_fetch_results`` calls (layer groups of one protein): they are carved one after another."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _RESULTS.get(key)
+    need = n_rows * width
+    if st is None or st['used'] + need > st['dev'].numel():
+        # (views handed out earlier keep their own storage alive; only new views come from the new buffer)
+        cap = max(1 << 16, 2 * need)
+        st = {'dev': torch.empty(cap, dtype=torch.int8, device=device), 'used': 0,
+              'pin': st['pin'] if st else torch.empty(1 << 16, dtype=torch.int8, pin_memory=True)}
+        _RESULTS[key] = st
+    view = st['dev'][st['used']:st['used'] + need].view(n_rows, width)
+    st['used'] += need
+    return view
+
+
+def _fetch_results(views):
+    """Device views handed out by ``_result_buffer`` -> numpy arrays (copies): asynchronous copies into one pinned
+    buffer and a single stream synchronisation for all of them."""
+    if not views:
+        return []
+    dev = views[0].device
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _RESULTS[key]
+    total = sum(v.numel() for v in views)
+    if st['pin'].numel() < total:
+        st['pin'] = torch.empty(2 * total, dtype=torch.int8, pin_memory=True)
+    pos = 0
+    for v in views:
+        n = v.numel()
+        st['pin'][pos:pos + n].copy_(v.reshape(-1), non_blocking=True)
+        pos += n
+    torch.cuda.current_stream(dev).synchronize()
+    flat = st['pin'][:total].numpy()
+    out, pos = [], 0
+    for v in views:
+        n = v.numel()
+        out.append(flat[pos:pos + n].reshape(v.shape).copy())
+        pos += n
+    st['used'] = 0
+    return out
 
 
 def _dtype_code(t: torch.Tensor) -> int:

@@ -17,7 +17,7 @@ from io import BytesIO
 import numpy as np
 
 from .database import Database
-from .similarity import l1_matrix, row_select
+from .similarity import l1_matrix, row_select, to_device_int8
 
 
 def _load_all(db: Database):
@@ -25,7 +25,7 @@ def _load_all(db: Database):
     meta, blobs = [], []
     for vid, pid, domain, blob in db.cur.execute('SELECT vid, pid, domain, fingerprint FROM fingerprints'):
         meta.append((vid, pid, domain))
-        blobs.append(np.load(BytesIO(blob), allow_pickle=True))
+        blobs.append(np.load(BytesIO(blob), allow_pickle=False))      # plain int8 vectors: no reason to unpickle a user's file
     return meta, np.array(blobs, dtype=np.int8)
 
 
@@ -34,9 +34,20 @@ def search(query_rows, query_fps, db_rows, db_fps, khits: int):
     sequences`` returns them: by primary key, i.e. sorted): the ``khits`` nearest database
     fingerprints of each of its fingerprints (ties: lower vid first, as a flat index scans), then
     all of those ranked by distance (stable) and the first ``khits`` printed (:33-59)."""
-    dist = l1_matrix(query_fps, db_fps)                                   # (nq, ndb) int32 on the GPU
+    # query fingerprints in tiles: the (tile, ndb) int32 distance matrix stays within ~1 GiB however large the database
+    # is (the reference streams one query protein at a time, src/query_db.py:75-87)
     k = min(khits, db_fps.shape[0])
-    dm, im = row_select(dist, k)                                          # k nearest per query fingerprint
+    db_dev = to_device_int8(db_fps)
+    tile = max(64, min(8192, (1 << 28) // max(1, db_fps.shape[0])))
+    dms, ims = [], []
+    for q0 in range(0, len(query_fps), tile):
+        dist = l1_matrix(query_fps[q0:q0 + tile], db_dev)                # (tile, ndb) int32 on the GPU
+        dm_t, im_t = row_select(dist, k)                                  # k nearest per query fingerprint
+        dms.append(dm_t)
+        ims.append(im_t)
+        del dist
+    dm = np.concatenate(dms) if dms else np.zeros((0, k), np.int64)
+    im = np.concatenate(ims) if ims else np.zeros((0, k), np.int64)
     by_pid = {}
     for qi, r in enumerate(query_rows):
         by_pid.setdefault(r[1], []).append(qi)

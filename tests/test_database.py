@@ -96,3 +96,39 @@ def test_yield_seqs_batches(tmp_path):
     assert [p for p, _ in db2.pending()] == ['b']
     db.close()
     db2.close()
+
+
+def test_flat_index_bytes_follow_the_published_faiss_layout(tmp_path):
+    """`.index` (src/database.py:240-243: faiss.IndexFlatL2(480) + faiss.write_index).  faiss is not installed here, so
+    the file cannot be read back by it -- parity stays UNPINNED -- but the serializer is held to the layout that faiss
+    1.7.4 publishes in faiss/impl/index_write.cpp, field by field, on a hand-built example:
+        write_index():         fourcc "IxF2" for an IndexFlat with METRIC_L2
+        write_index_header():  d (int32), ntotal (int64), two dummies 1 << 20 (int64 each), is_trained (1 byte),
+                               metric_type (int32, METRIC_L2 = 1; metric_arg only follows for metric_type > 1)
+        WRITEXBVECTOR(codes):  codes.size() / 4 (uint64) = ntotal * d, then the float32 values row by row."""
+    import struct
+    from dctdomain_amd.database import read_flat_index, write_flat_index
+    vec = np.array([[0, 127, 5], [1, 2, 3]], dtype=np.float32)
+    path = str(tmp_path / 't.index')
+    write_flat_index(path, vec)
+    expected = b''.join([
+        b'IxF2',
+        struct.pack('<i', 3),                      # d
+        struct.pack('<q', 2),                      # ntotal
+        struct.pack('<q', 1 << 20),                # dummy
+        struct.pack('<q', 1 << 20),                # dummy
+        b'\x01',                                   # is_trained
+        struct.pack('<i', 1),                      # METRIC_L2
+        struct.pack('<Q', 6),                      # codes.size() / 4
+        struct.pack('<6f', 0, 127, 5, 1, 2, 3),    # codes
+    ])
+    assert open(path, 'rb').read() == expected
+    assert len(expected) == 4 + 4 + 8 + 16 + 1 + 4 + 8 + 24
+    np.testing.assert_array_equal(read_flat_index(path), vec)
+    # the production shape: int8 fingerprints cast to float32, 480 wide
+    fps = np.arange(3 * 480, dtype=np.int64).reshape(3, 480) % 128
+    write_flat_index(path, fps.astype(np.int8).astype(np.float32))
+    raw = open(path, 'rb').read()
+    assert raw[:4] == b'IxF2' and struct.unpack('<i', raw[4:8])[0] == 480 and struct.unpack('<q', raw[8:16])[0] == 3
+    assert len(raw) == 45 + 3 * 480 * 4
+    np.testing.assert_array_equal(np.frombuffer(raw[45:], dtype=np.float32).reshape(3, 480), fps.astype(np.float32))

@@ -91,3 +91,72 @@ def test_cli_outputs_and_two_workers(tmp_path):
     for k in za.files:
         np.testing.assert_array_equal(za[k], zb[k])
     assert open(a + '.dom').read() == open(b + '.dom').read()
+
+
+def test_config5_scale_build_two_workers_against_one_and_oracle(tmp_path):
+    """BASELINE config 5, scaled to one GPU box: 5 200 proteins with pfam-like lengths (81..1330) through the
+    make_db drop-in -- two worker processes against one (identical files: the single writer commits every flush in
+    sequence order), then a sample of proteins recomputed by the CPU chain (oracle top-k -> the reference's RecCut
+    binary when it is there -> oracle quantize) against the rows of the written -dct.npz."""
+    from dctdomain_amd import make_db
+    from dctdomain_amd.embedding import Batch, SyntheticModel
+    from oracle import contacts_oracle as co
+    from oracle import dct_oracle as orc
+    rng = np.random.default_rng(55)
+    n_prot = 5200
+    lengths = np.clip(rng.gamma(2.2, 170.0, size=n_prot).astype(np.int64), 81, 1330)
+    fa = str(tmp_path / 'c5.fasta')
+    seqs = {}
+    with open(fa, 'w') as fh:
+        for i, L in enumerate(lengths):
+            s = ''.join('ACDEFGHIKLMNPQRSTVWY'[int(v)] for v in rng.integers(0, 20, size=int(L)))
+            seqs[f'P{i:05d}'] = s
+            fh.write(f'>P{i:05d} synthetic\n{s}\n')
+
+    def build(name, extra):
+        dbfile = str(tmp_path / name)
+        make_db.main(['--fafile', fa, '--dbfile', dbfile, '--model', 'synthetic', '--cpu', '8', '--noindex',
+                      '--flush', '512', '--out', str(tmp_path / f'{name}.log')] + extra)
+        return dbfile
+
+    two = build('two', ['--gpu', '2'])
+    one = build('one', [])
+    za, zb = np.load(one + '-dct.npz'), np.load(two + '-dct.npz')
+    for k in za.files:
+        np.testing.assert_array_equal(za[k], zb[k])
+    assert open(one + '.dom').read() == open(two + '.dom').read()
+    assert za['sid'].shape == (n_prot,) and za['dct'].shape[1] == 480 and za['dct'].shape[0] == za['idx'][-1]
+    assert za['dct'].shape[0] > 2 * n_prot                      # mostly multi-domain: parts + whole protein
+    # table order = ascending length (stable), whatever the number of workers
+    assert list(za['sid']) == sorted(seqs, key=lambda p: len(seqs[p]))
+    rows = za['dct'].reshape(-1, 6, 80)
+    assert ((rows == 127).sum(axis=2) == 1).all() and ((rows == 0).sum(axis=2) >= 1).all()
+    # the database is complete and resumable: nothing pending, fpcount = rows per protein
+    from dctdomain_amd.database import Database
+    db = Database(two + '.db')
+    assert db.pending() == []
+    db.close()
+
+    # sample: CPU chain on the same embeddings
+    dev = torch.device('cuda', 0)
+    model = SyntheticModel()
+    model.to_device(dev)
+    sid = list(za['sid'])
+    n_multi = 0
+    for pid in [sid[i] for i in (0, 7, 601, 1999, 2600, 3333, 4100, 4800, 5100, 5199)]:
+        b = Batch([(pid, seqs[pid])], model, dev)
+        b.embed_batch([15, 21], 500)
+        e = b.embeds[0]
+        ct = e.contacts.cpu().numpy()
+        ci, cj, cv = co.top_contacts(ct, 2.6)
+        k = sid.index(pid)
+        doms = [str(d) for d in za['dom'][za['idx'][k]:za['idx'][k + 1]]]
+        if os.path.exists(co.REF_BIN):
+            rc, out = co.run_ref_binary(co.ce_text(pid, seqs[pid], ci, cj, cv), pid)
+            assert rc == 0 and co.parse_reccut(out, len(seqs[pid])) == doms
+        q = orc.quantize([e.embed[15].cpu().numpy(), e.embed[21].cpu().numpy()], doms, [3, 80, 3, 80])
+        assert list(q) == doms
+        for r, key in enumerate(doms):
+            np.testing.assert_array_equal(za['dct'][za['idx'][k] + r].astype(np.int64), q[key], err_msg=f'{pid} {key}')
+        n_multi += len(doms) > 1
+    assert n_multi >= 5

@@ -30,3 +30,11 @@ while time.perf_counter() - t0 < 3.0:
     n += 1
 dt = time.perf_counter() - t0
 print(f'GPU tensors in, one protein per call: {n / dt:.0f} fingerprints/s ({1e3 * dt / n:.3f} ms per call)')
+if len(sys.argv) > 1 and sys.argv[1] == 'profile':
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(2000):
+        one(dev[i % len(dev)])
+    pr.disable()
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
