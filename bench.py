@@ -94,6 +94,16 @@ def make_workload(args, rank, np):
     return lengths, doms, args.dim or dim
 
 
+def source_sha256() -> str:
+    """sha256 over the kernel sources: what a PMC traffic measurement is valid for."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ('dctdomain_amd/csrc/kernels.hip.h', 'dctdomain_amd/csrc/dctfp.hip'):
+        with open(os.path.join(ROOT, name), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without torchrun: start the N ranks as children of this process
     (`python -m torch.distributed.run`, rendezvous on 127.0.0.1), pass rank 0's JSON line through and
@@ -214,11 +224,21 @@ def main():
         a_launch_ms = ms_k[0] / max(1, n_k[0])
         a_bytes = batch_bytes * (args.steps / max(1, n_k[0]))               # units one stage-A launch processes
         achieved = a_bytes / (a_launch_ms * 1e-3) / 1e9 if a_launch_ms > 0 else 0.0
-        traffic = None
+        # HBM traffic of the dominant kernel from the PMC passes (tools/profile_gpu.sh).  The file is stamped with the sha256
+        # of the kernel sources it was measured on; a stamp that does not match the sources of THIS run means the number is
+        # stale -> null, never a silently outdated constant.
+        kernel = 'walk_ab_kernel' if ctx.get_option('last_path') == 2 else 'stage_a_kernel'
+        traffic, traffic_note = None, 'no PMC measurement for this workload / source state'
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tfile) and args.workload == 'c2' and n_seq == 10000 and L == 500 and D == 1280:
+        if os.path.exists(tfile):
             with open(tfile) as fh:
-                traffic = json.load(fh).get('stage_a_hbm_bytes_per_launch')
+                tj = json.load(fh)
+            entry = tj.get('workloads', {}).get(args.workload)
+            same_shape = args.workload != 'c2' or (n_seq == 10000 and L == 500 and D == 1280)
+            if entry and tj.get('source_sha256') == source_sha256() and entry.get('kernel') == kernel and same_shape \
+                    and not args.opt and args.storage == 'float32':
+                traffic = entry['hbm_bytes_per_launch']
+                traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {tj.get('measured', '')}: 2 x FETCH_SIZE KiB + WRITE_SIZE KiB"
         line = {
             'metric': 'DCT fingerprints/sec on L=500 D=1280' if args.workload == 'c2' else f'DCT fingerprints/sec ({args.workload})', 'value': value, 'unit': 'fingerprints/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -237,8 +257,8 @@ def main():
                        'sequences_per_gpu': n_seq, 'fingerprints_per_gpu': n_fp, 'L': L if args.workload == 'c2' else None,
                        'D': D, 'layers': args.layers, 'sharding': f'seq{world}'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'stage_a_kernel', 'avg_launch_ms': a_launch_ms,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_note,
+                         'kernel': kernel, 'avg_launch_ms': a_launch_ms,
                          'algorithmic_bytes_per_launch': a_bytes,
                          'stage_b_avg_launch_ms': ms_k[1] / max(1, n_k[1]),
                          'whole_path_GBps': value / world * bytes_per_fp / 1e9},

@@ -122,20 +122,38 @@ class LayerBatch:
         self.m_keep = int(m_keep)
 
 
+def host_pointer(t: torch.Tensor) -> int:
+    """The address under which the GPU sees a pinned host tensor (``dctfp_host_device_pointer``); raises when the
+    tensor is not page-locked and mapped."""
+    if not t.is_pinned():
+        raise ValueError('a host tensor used as the result buffer must be pinned (pin_memory=True)')
+    dev = C.c_void_p()
+    _lib.check(_lib.load().dctfp_host_device_pointer(C.c_void_p(t.data_ptr()), C.byref(dev)))
+    return dev.value
+
+
 def quantize_batch(layers: Sequence[LayerBatch], table: PieceTable, out: torch.Tensor = None,
                    ctx: _lib.Context = None, stream=None) -> torch.Tensor:
     """Runs ``dctfp_quantize`` (include/dctfp.h) and returns the int8 tensor
     ``(table.n_domains, sum n_i*m_i)`` on the layers' device.  Asynchronous with respect
-    to the host: the result is ordered on the given / current torch stream."""
+    to the host: the result is ordered on the given / current torch stream.  ``out`` may be a
+    pinned host tensor: then the result lands in host memory without a copy (valid once the
+    stream has been synchronised)."""
     if not layers:
         raise ValueError('no layers')
     device = layers[0].device
     total = sum(l.n_keep * l.m_keep for l in layers)
+    out_ptr = None
     if out is None:
         out = torch.empty((table.n_domains, total), dtype=torch.int8, device=device)
     elif out.dtype != torch.int8 or out.dim() != 2 or out.shape[0] < table.n_domains or out.shape[1] < total \
-            or out.stride(1) != 1 or out.device != device:
-        raise ValueError('out must be an int8 (n_domains, >= sum n*m) tensor on the same device')
+            or out.stride(1) != 1:
+        raise ValueError('out must be an int8 (n_domains, >= sum n*m) tensor')
+    elif out.device.type == 'cpu':
+        # a pinned host tensor: the kernels write the result over PCIe themselves (small calls; see host_pointer)
+        out_ptr = host_pointer(out)
+    elif out.device != device:
+        raise ValueError('out must live on the layers\' device (or be a pinned host tensor)')
     if table.n_domains == 0:
         return out
     if ctx is None:
@@ -158,6 +176,6 @@ def quantize_batch(layers: Sequence[LayerBatch], table: PieceTable, out: torch.T
         stream = torch.cuda.current_stream(device)
     rc = ctx._lib.dctfp_quantize(ctx.handle, arr, len(layers), n_seq, table.seq_rows.ctypes.data,
                                  table.pieces.ctypes.data, len(table.pieces), table.n_domains,
-                                 out.data_ptr(), out.stride(0), C.c_void_p(stream.cuda_stream))
+                                 out.data_ptr() if out_ptr is None else out_ptr, out.stride(0), C.c_void_p(stream.cuda_stream))
     _lib.check(rc)
     return out

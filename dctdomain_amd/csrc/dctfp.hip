@@ -92,8 +92,9 @@ struct DevBuf {
     }
 };
 
-struct Staging {  // pinned host buffer + the event after its last H2D copy
+struct Staging {  // pinned host buffer + the event after its last H2D copy (or after its last reader on the GPU)
     void* p = nullptr;
+    void* dev = nullptr;  // the same buffer as the GPU addresses it (nullptr: not mapped, copy instead)
     size_t cap = 0;
     hipEvent_t ev = nullptr;
     bool pending = false;
@@ -110,6 +111,7 @@ struct Staging {  // pinned host buffer + the event after its last H2D copy
         if (bytes <= cap) return DCTFP_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr;
+        dev = nullptr;
         cap = 0;
         size_t want = bytes + bytes / 2 + 4096;
         hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
@@ -118,6 +120,11 @@ struct Staging {  // pinned host buffer + the event after its last H2D copy
             return fail(DCTFP_ERR_NOMEM, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
         }
         cap = want;
+        dev = nullptr;
+        if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) {
+            dev = nullptr;
+            (void)hipGetLastError();
+        }
         return DCTFP_OK;
     }
     void release() {
@@ -202,6 +209,7 @@ struct dctfp_ctx {
     size_t basis_doubles = 0;
     unsigned long long* degenerate = nullptr;  // device counter: exactly constant channels seen (see dctfp.h)
     int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0;
+    int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     std::map<std::pair<int, int>, StEntry> st_cache;
     uint64_t tick = 0;
     std::vector<EventPair> events;
@@ -681,6 +689,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     else if (n == "a_unroll") *value = ctx->opt_a_unroll;
     else if (n == "overlap") *value = ctx->opt_overlap;
     else if (n == "path") *value = ctx->opt_path;
+    else if (n == "last_path") *value = ctx->last_path;
     else if (n == "ab_group") *value = ctx->opt_ab_group;
     else if (n == "ab_unroll") *value = ctx->opt_ab_unroll;
     else if (n == "ab_run_jobs") *value = ctx->opt_ab_run_jobs;
@@ -1079,12 +1088,17 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         // (a small call keeps everything on the caller's stream: the hop through the copy stream costs two event waits,
         //  more than the upload itself)
         const bool inline_tables = tab_bytes <= (64u << 10) && n_jobs < 512;
+        // ... and read the few hundred bytes of tables straight from the pinned staging buffer: an upload through the copy
+        // engine costs more latency than the kernels of such a call take
+        const bool zero_copy = inline_tables && stg.dev != nullptr;
         hipStream_t ts = inline_tables ? stream : ctx->copy;
-        if (ctx->tab_busy[buf]) HIP_TRY(hipStreamWaitEvent(ts, ctx->ev_tab_free[buf], 0));
-        HIP_TRY(hipMemcpyAsync(tab.p, stg.p, tab_bytes, hipMemcpyHostToDevice, ts));
-        HIP_TRY(hipEventRecord(stg.ev, ts));
-        stg.pending = true;
-        char* dt = (char*)tab.p;
+        if (!zero_copy) {
+            if (ctx->tab_busy[buf]) HIP_TRY(hipStreamWaitEvent(ts, ctx->ev_tab_free[buf], 0));
+            HIP_TRY(hipMemcpyAsync(tab.p, stg.p, tab_bytes, hipMemcpyHostToDevice, ts));
+            HIP_TRY(hipEventRecord(stg.ev, ts));
+            stg.pending = true;
+        }
+        char* dt = zero_copy ? (char*)stg.dev : (char*)tab.p;
         const JobB* djb = (const JobB*)(dt + off_jobb);
         const JobA* dja = (const JobA*)(dt + off_joba);
         const PieceA* dpc = (const PieceA*)(dt + off_piece);
@@ -1103,6 +1117,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(ctx->ev_tab_free[buf], stream));
             ctx->tab_busy[buf] = true;
+            if (zero_copy) {  // the kernels read the staging buffer itself: it is free again after them
+                HIP_TRY(hipEventRecord(stg.ev, stream));
+                stg.pending = true;
+            }
             l0 = l1;
             continue;
         }
@@ -1134,6 +1152,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         // tables cached by an earlier call may have been filled on another stream
         if (ctx->basis_valid && ctx->basis_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_basis, 0));
 
+        ctx->last_path = use_walk ? 2 : 1;
         if (use_walk) {
             // one launch: stage A + stage B per workgroup, int8 out
             EventPair* ep = nullptr;
@@ -1160,6 +1179,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             if (rc) return rc;
             HIP_TRY(hipEventRecord(ctx->ev_tab_free[buf], stream));
             ctx->tab_busy[buf] = true;
+            if (zero_copy) {  // the kernels read the staging buffer itself: it is free again after them
+                HIP_TRY(hipEventRecord(stg.ev, stream));
+                stg.pending = true;
+            }
             l0 = l1;
             continue;
         }
@@ -1204,11 +1227,18 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 ap.grid = (unsigned)(ck.wn * n_slabs);
                 ap.stream = stream;
                 int waves = (int)ctx->opt_a_waves;
+                int unroll = (int)ctx->opt_a_unroll;
                 if (waves == 0) {  // auto: short walks want more, smaller workgroups per CU
                     waves = avg_rows >= 320 ? 8 : (avg_rows >= 160 ? 4 : 2);
+                    // a call that cannot fill the chip (a protein at a time) is bound by the latency of one workgroup:
+                    // as many waves and rows in flight as a workgroup can have
+                    if (ck.wn * n_slabs < 256 && avg_rows >= 128 && vec == 4) {
+                        waves = 16;
+                        if (!fuse) unroll = 8;
+                    }
                     if (vec == 8 && waves > 4) waves = 4;  // 8 channels per lane: keep the LDS reduction buffer small
                 }
-                launch_a(ap, g.dtype, vec, n, waves, (int)ctx->opt_a_unroll);
+                launch_a(ap, g.dtype, vec, n, waves, unroll);
                 HIP_TRY(hipGetLastError());
             }
             rc = prof_end(ep, stream);
@@ -1242,6 +1272,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         ctx->ws_busy = true;
         HIP_TRY(hipEventRecord(ctx->ev_tab_free[buf], stream));  // this table buffer may be overwritten after this point
         ctx->tab_busy[buf] = true;
+        if (zero_copy) {
+            HIP_TRY(hipEventRecord(stg.ev, stream));
+            stg.pending = true;
+        }
         l0 = l1;
     }
     return DCTFP_OK;
@@ -1331,8 +1365,8 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
                        int32_t n_prot, double t, int32_t* out_i, int32_t* out_j, float* out_v,
                        const int64_t* out_offs, int32_t* out_n, void* stream_v) {
     if (!ctx || !maps || !ld || !n_res || !out_i || !out_j || !out_v || !out_offs || !out_n)
-    std::lock_guard<std::mutex> lock(ctx->mu);
         return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     if (n_prot < 0) return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: negative count");
     if (n_prot == 0) return DCTFP_OK;
     hipStream_t stream = (hipStream_t)stream_v;
@@ -1476,6 +1510,18 @@ int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_
     hipLaunchKernelGGL(row_select_kernel, dim3((unsigned)n_rows), dim3(1024), 0, (hipStream_t)stream_v, dist, ld, n_cols, k,
                        out_val, out_idx);
     HIP_TRY(hipGetLastError());
+    return DCTFP_OK;
+}
+
+int dctfp_host_device_pointer(void* host, void** dev) {
+    if (!host || !dev) return fail(DCTFP_ERR_INVALID, "dctfp_host_device_pointer: NULL argument");
+    *dev = nullptr;
+    hipError_t e = hipHostGetDevicePointer(dev, host, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *dev = nullptr;
+        return fail(DCTFP_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
+    }
     return DCTFP_OK;
 }
 

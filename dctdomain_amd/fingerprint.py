@@ -200,7 +200,7 @@ class Fingerprint:
                 quantize_batch(layers, table, out=out)
                 groups.append((table, out, i, j))
             i = j + 1
-        hosts = _fetch_results([g[1] for g in groups])
+        hosts = _fetch_results([g[1] for g in groups], mats[0].device if mats else None)
 
         # quants[key] = the blocks of every layer, layer-major, then domain order (:184-196); a key that occurs
         # twice (two domain strings cleaned to the same key) is extended twice, as there
@@ -220,51 +220,32 @@ class Fingerprint:
         self.domains = list(self.quants.keys())
 
 
-# per-device scratch of the one-protein-per-call path: an int8 result buffer on the GPU and its pinned twin
-_RESULTS = {}
+# scratch of the one-protein-per-call path: a pinned host buffer the kernels write their int8 results into directly
+# (480 bytes per domain over PCIe: no device buffer, no copy engine in the chain -- its latency was most of a call)
+_RESULTS = {'pin': None, 'used': 0}
 
 
 def _result_buffer(device, n_rows: int, width: int) -> torch.Tensor:
-    """A (n_rows, width) int8 view of a reusable device buffer -- no allocation per call.  Several views may be
-    handed out between two ``_fetch_results`` calls (layer groups of one protein): they are carved one after another."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    st = _RESULTS.get(key)
+    """A (n_rows, width) int8 view of the pinned result buffer.  Several views may be handed out between two
+    ``_fetch_results`` calls (layer groups of one protein): they are carved one after another."""
+    st = _RESULTS
     need = n_rows * width
-    if st is None or st['used'] + need > st['dev'].numel():
-        # (views handed out earlier keep their own storage alive; only new views come from the new buffer)
-        cap = max(1 << 16, 2 * need)
-        st = {'dev': torch.empty(cap, dtype=torch.int8, device=device), 'used': 0,
-              'pin': st['pin'] if st else torch.empty(1 << 16, dtype=torch.int8, pin_memory=True)}
-        _RESULTS[key] = st
-    view = st['dev'][st['used']:st['used'] + need].view(n_rows, width)
+    if st['pin'] is None or st['used'] + need > st['pin'].numel():
+        # (views handed out earlier keep their storage alive; only new views come from the new buffer)
+        st['pin'] = torch.empty(max(1 << 16, 2 * need), dtype=torch.int8, pin_memory=True)
+        st['used'] = 0
+    view = st['pin'][st['used']:st['used'] + need].view(n_rows, width)
     st['used'] += need
     return view
 
 
-def _fetch_results(views):
-    """Device views handed out by ``_result_buffer`` -> numpy arrays (copies): asynchronous copies into one pinned
-    buffer and a single stream synchronisation for all of them."""
+def _fetch_results(views, device=None):
+    """Views handed out by ``_result_buffer`` -> numpy arrays (copies) after ONE stream synchronisation."""
     if not views:
         return []
-    dev = views[0].device
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = _RESULTS[key]
-    total = sum(v.numel() for v in views)
-    if st['pin'].numel() < total:
-        st['pin'] = torch.empty(2 * total, dtype=torch.int8, pin_memory=True)
-    pos = 0
-    for v in views:
-        n = v.numel()
-        st['pin'][pos:pos + n].copy_(v.reshape(-1), non_blocking=True)
-        pos += n
-    torch.cuda.current_stream(dev).synchronize()
-    flat = st['pin'][:total].numpy()
-    out, pos = [], 0
-    for v in views:
-        n = v.numel()
-        out.append(flat[pos:pos + n].reshape(v.shape).copy())
-        pos += n
-    st['used'] = 0
+    torch.cuda.current_stream(device).synchronize()
+    out = [v.numpy().copy() for v in views]
+    _RESULTS['used'] = 0
     return out
 
 

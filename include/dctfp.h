@@ -176,10 +176,16 @@ int dctfp_block_min(dctfp_ctx* ctx, const int32_t* dist, int64_t ldo, const int6
 int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k,
                      int32_t* out_val, int32_t* out_idx, void* stream);
 
+/* The address under which the GPU sees a pinned (page-locked, mapped) host buffer, e.g. a torch tensor created with
+ * pin_memory=True.  A caller that passes this address as `out` of dctfp_quantize gets the int8 result written straight
+ * into host memory: no device buffer, no copy -- what a one-protein-per-call user wants (480 bytes per domain). */
+int dctfp_host_device_pointer(void* host, void** dev);
+
 /* Tuning / instrumentation knobs (no reference counterpart).
  *   "path"         0 (default) = by shape: the walk kernel (stage A + stage B in one launch, nothing but int8 written)
  *                  for n = 3, 64 < m <= 80, float32 rows, 512 <= D <= 1280; stage A -> scratch -> stage B otherwise;
  *                  1 = always the two-kernel path; 2 = the walk kernel wherever its shapes allow (also D <= 2560)
+ *   "last_path"    read only: which kernels the last dctfp_quantize launched (1 = two kernels, 2 = walk kernel)
  *   "ab_group"     walk kernel: jobs per stage-B flush (0 = by shape, 2..4)
  *   "ab_unroll"    walk kernel: rows in flight per wave (0 = by shape, 4, 8)
  *   "ab_run_jobs"  walk kernel: jobs per workgroup (0 = by batch size)

@@ -16,7 +16,7 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 echo "== pmc WRITE_SIZE" | tee -a "$OUT/log.txt"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps 2 --warmup 1 >> "$OUT/log.txt" 2>&1 || exit 1
 echo "== pmc SQ busy / valu / mfma" | tee -a "$OUT/log.txt"
-timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- $BENCH --steps 2 --warmup 1 >> "$OUT/log.txt" 2>&1 || echo "sq pass failed (non fatal)" | tee -a "$OUT/log.txt"
+timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- $BENCH --steps 2 --warmup 1 >> "$OUT/log.txt" 2>&1 || echo "sq pass failed (non fatal)" | tee -a "$OUT/log.txt"
 cd "$REPO"
 python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.md" 2>> "$OUT/log.txt"
 # keep only the small files
