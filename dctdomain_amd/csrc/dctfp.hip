@@ -203,6 +203,7 @@ struct dctfp_ctx {
     DevBuf ws;       // yprime
     int64_t opt_fuse = 1, opt_pack_y = 1;
     DevBuf scratch;  // generic idct_quant fs
+    DevBuf split_ws; // partial sums of the row-split stage A (small calls)
     // stage-A cosine tables, one per (domain length, n - 1): filled once, kept for the life of the context
     std::vector<BasisSlab> basis_slabs;
     std::unordered_map<uint64_t, double*> basis_tabs;
@@ -602,6 +603,7 @@ int dctfp_destroy(dctfp_ctx* ctx) {
     for (auto& s : ctx->staging) s.release();
     ctx->ws.release();
     ctx->scratch.release();
+    ctx->split_ws.release();
     for (auto& kv : ctx->st_cache) {
         (void)hipFree(kv.second.dev);
         if (kv.second.frag) (void)hipFree(kv.second.frag);
@@ -905,7 +907,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         for (size_t i = 0; i < fresh.size(); ++i) hbt[i] = fresh[i];
 
         const int ldy_pre = (int)align_up((size_t)g.n_cols, 32);
-        const bool fuse = !trivial && n_groups > 0;
+        // (a small call wants parallelism, not fewer bytes: every job on its own workgroups)
+        const bool fuse = !trivial && n_groups > 0 && n_jobs >= 64;
         bool vec_ok = true;
         for (int li = 0; li < ng; ++li) {
             const dctfp_layer& ly = layers[l0 + li];
@@ -1015,7 +1018,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         }
         std::vector<Chunk> plan;
         // Y' per job: n float64 rows, or (n = 3 with the MFMA stage B) one float64 t row + one state byte per channel
-        const bool packed = ctx->opt_pack_y && n == 3 && ctx->opt_stage_b == 1;
+        // (a handful of jobs: the MFMA stage B would walk the D channels in 80 dependent steps inside one workgroup --
+        //  ~80 us of latency; the plain kernel, one workgroup per job, is done in a tenth of that)
+        const bool small_b = n_jobs < 32 && ctx->opt_stage_b == 1;
+        const bool packed = ctx->opt_pack_y && n == 3 && ctx->opt_stage_b == 1 && !small_b;
         const size_t job_bytes = packed ? (size_t)ldy_pre * 9 : (size_t)n * ldy_pre * sizeof(double);
         const int n_slabs = (ldy_pre + 64 * vec - 1) / (64 * vec);
         int slots = 1;
@@ -1226,6 +1232,25 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 ap.n_slabs = n_slabs;
                 ap.grid = (unsigned)(ck.wn * n_slabs);
                 ap.stream = stream;
+                // a call that cannot fill the chip: split the rows of every job over workgroups (stage_a_split_kernel)
+                const bool split = !fuse && n == 3 && g.dtype == DCTFP_F32 && vec == 4 && ctx->opt_a_waves == 0 &&
+                                   jn * n_slabs < 128 && avg_rows >= 128 && max_len_all <= (1u << 24);
+                if (split) {
+                    int64_t want_chunks = std::min<int64_t>(32, std::max<int64_t>(2, 384 / (jn * n_slabs)));
+                    uint32_t chunk_rows = (uint32_t)((max_len_all + want_chunks - 1) / want_chunks);
+                    chunk_rows = std::max<uint32_t>(32, (chunk_rows + 31) / 32 * 32);  // 8 waves x 4 rows in flight
+                    const int n_chunks = (int)((max_len_all + chunk_rows - 1) / chunk_rows);
+                    rc = ctx->split_ws.ensure((size_t)jn * n_chunks * nk * ldy * sizeof(double));
+                    if (rc) return rc;
+                    static const InvTab<3> inv3 = make_inv<3>();
+                    hipLaunchKernelGGL((stage_a_split_kernel<float, 3, 4, 8, 4>), dim3((unsigned)(jn * n_chunks * n_slabs)), dim3(512), 0, stream,
+                                       dja + j0, dpc, (double*)ctx->split_ws.p, n_chunks, chunk_rows, g.n_cols, g.ld, ldy, n_slabs);
+                    HIP_TRY(hipGetLastError());
+                    hipLaunchKernelGGL((stage_a_combine_kernel<3>), dim3((unsigned)((ldy + 255) / 256), (unsigned)jn), dim3(256), 0, stream,
+                                       (const double*)ctx->split_ws.p, n_chunks, yprime, (int64_t)job_bytes, packed ? 1 : 0, g.n_cols, ldy,
+                                       inv3, ctx->degenerate);
+                    HIP_TRY(hipGetLastError());
+                }
                 int waves = (int)ctx->opt_a_waves;
                 int unroll = (int)ctx->opt_a_unroll;
                 if (waves == 0) {  // auto: short walks want more, smaller workgroups per CU
@@ -1238,7 +1263,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                     }
                     if (vec == 8 && waves > 4) waves = 4;  // 8 channels per lane: keep the LDS reduction buffer small
                 }
-                launch_a(ap, g.dtype, vec, n, waves, unroll);
+                if (!split) launch_a(ap, g.dtype, vec, n, waves, unroll);
                 HIP_TRY(hipGetLastError());
             }
             rc = prof_end(ep, stream);
@@ -1250,12 +1275,12 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
 
             rc = prof_begin(ctx, 1, sb, &ep);
             if (rc) return rc;
-            if (ctx->opt_stage_b == 1) {
+            if (ctx->opt_stage_b == 1 && !small_b) {
                 const int64_t rows = jn * n;
                 launch_b_mfma(st->cp / 16, packed, (unsigned)((rows + kBWaves * 16 - 1) / (kBWaves * 16)), sb, yprime, (int64_t)job_bytes, rows, ldy,
                               st->dev, djb + j0, n, m, out);
             } else {
-                hipLaunchKernelGGL(stage_b_valu_kernel, dim3((unsigned)jn), dim3(256), 0, sb, (const double*)yprime, ldy, g.n_cols,
+                hipLaunchKernelGGL(stage_b_valu_kernel, dim3((unsigned)jn), dim3(1024), 0, sb, (const double*)yprime, ldy, g.n_cols,
                                    st->dev, st->cp, djb + j0, n, m, out);
             }
             HIP_TRY(hipGetLastError());

@@ -412,6 +412,108 @@ __global__ __launch_bounds__(WAVES * 64, (FUSED && N == 3 && VEC == 4 && UNROLL 
 }
 
 // ---------------------------------------------------------------------------
+// K1s: stage A split over the rows -- for calls too small to fill the chip (a protein per call, the reference's calling
+// pattern: 2 layers x 5 slabs = 10 workgroups would stream 5 MB on 10 of 256 CUs).  Workgroup = (job, chunk of
+// `chunk_rows` rows, slab): same arithmetic as stage_a_kernel (first-row shift of the JOB, the job's cosine table), but the
+// partial sums go to a scratch; stage_a_combine_kernel adds the chunks in order (deterministic) and runs the epilogue.
+// ---------------------------------------------------------------------------
+template <typename T, int N, int VEC, int WAVES, int UNROLL>
+__global__ __launch_bounds__(WAVES * 64) void stage_a_split_kernel(const JobA* __restrict__ jobs, const PieceA* __restrict__ pieces,
+                                                                    double* __restrict__ partial, int n_chunks, uint32_t chunk_rows,
+                                                                    int n_cols, int64_t ld, int ldy, int n_slabs) {
+    constexpr int NK = N - 1;
+    __shared__ double red[WAVES][NK * VEC][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t slab = blockIdx.x % (uint32_t)n_slabs;
+    const uint32_t jc = blockIdx.x / (uint32_t)n_slabs;
+    const uint32_t chunk = jc % (uint32_t)n_chunks, job_id = jc / (uint32_t)n_chunks;
+    const int col0 = ((int)slab * 64 + lane) * VEC;
+    const int colc = (col0 < n_cols) ? col0 : 0;
+    const JobA job = jobs[job_id];
+    const PieceA* __restrict__ pc = pieces + job.piece_begin;
+    const uint32_t lo = chunk * chunk_rows;
+    const uint32_t hi = min(job.n_rows, lo + chunk_rows);  // this workgroup's rows of the job: [lo, hi)
+    double acc[NK][VEC];
+    double ref[VEC];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[k][v] = 0.0;
+    if (lo < hi) {
+        {
+            auto r0 = load_raw<T, VEC>(reinterpret_cast<const T*>(pc[0].ptr) + colc);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) ref[v] = raw_elem<T, VEC>(r0, v);
+        }
+        const CosTab bt = cos_tab(job.basis);
+        for (uint32_t p = 0; p < job.n_pieces; ++p) {
+            const PieceA piece = pc[p];
+            const uint32_t a = max(lo, piece.t0), b = min(hi, piece.t0 + piece.n_rows);  // job rows of this piece in the chunk
+            if (a >= b) continue;
+            const T* __restrict__ base = reinterpret_cast<const T*>(piece.ptr) + colc;
+            auto row_update = [&](const typename Raw<T, VEC>::type& x, uint32_t t) {  // t = row of the job
+                const CosTab c = bt + (size_t)t * NK;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const double d = raw_elem<T, VEC>(x, v) - ref[v];
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) acc[k][v] = fma(c[k], d, acc[k][v]);
+                }
+            };
+            uint32_t t = a + (uint32_t)wave;
+            for (; t + (UNROLL - 1) * WAVES < b; t += UNROLL * WAVES) {
+                typename Raw<T, VEC>::type xv[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) xv[u] = load_raw<T, VEC>(base + (size_t)(t + u * WAVES - piece.t0) * ld);
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) row_update(xv[u], t + u * WAVES);
+            }
+            for (; t < b; t += WAVES) {
+                auto x1 = load_raw<T, VEC>(base + (size_t)(t - piece.t0) * ld);
+                row_update(x1, t);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[wave][k * VEC + v][lane] = acc[k][v];
+    __syncthreads();
+    for (int cl = threadIdx.x; cl < 64 * VEC; cl += WAVES * 64) {
+        const int ln = cl / VEC, v = cl % VEC;
+        const int col = (int)slab * 64 * VEC + cl;
+        if (col >= ldy) continue;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            double sum = red[0][k * VEC + v][ln];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) sum += red[w][k * VEC + v][ln];
+            partial[((size_t)jc * NK + k) * ldy + col] = sum;
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void stage_a_combine_kernel(const double* __restrict__ partial, int n_chunks, char* __restrict__ yprime,
+                                                               int64_t job_bytes, int packed, int n_cols, int ldy, InvTab<N> inv,
+                                                               unsigned long long* __restrict__ degenerate) {
+    constexpr int NK = N - 1;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t job_id = blockIdx.y;
+    if (col >= ldy) return;
+    double f[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) f[k] = 0.0;
+    for (int c = 0; c < n_chunks; ++c)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) f[k] += partial[(((size_t)job_id * n_chunks + c) * NK + k) * ldy + col];
+    char* __restrict__ jb = yprime + (size_t)job_id * job_bytes;
+    finish_channel<N>(f, inv, reinterpret_cast<double*>(jb) + col, ldy, col >= n_cols, packed != 0,
+                      jb + (size_t)ldy * sizeof(double) + col, degenerate);
+}
+
+// ---------------------------------------------------------------------------
 // Shared epilogue helper: trunc(127 z) with NaN / out-of-range -> 0
 // ((ddct*127).astype('int8'), src/fingerprint.py:195; x86 numpy gives 0 for NaN).
 // ---------------------------------------------------------------------------
@@ -572,44 +674,57 @@ __global__ __launch_bounds__(kBWaves * 64, MINW) void stage_b_mfma_kernel(const 
 // K2 (VALU): same result as the MFMA kernel, one workgroup per job, plain FMAs.
 // Kept as the cross-check of the MFMA fragment layout and for A/B timing.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stage_b_valu_kernel(const double* __restrict__ yp, int ldy, int n_cols,
-                                                            const double* __restrict__ st, int cp,
-                                                            const JobB* __restrict__ jobs, int n, int m,
-                                                            int8_t* __restrict__ out) {
+__global__ __launch_bounds__(1024) void stage_b_valu_kernel(const double* __restrict__ yp, int ldy, int n_cols,
+                                                             const double* __restrict__ st, int cp,
+                                                             const JobB* __restrict__ jobs, int n, int m,
+                                                             int8_t* __restrict__ out) {
+    // 1024 threads = 4 groups x 256: group kg takes every fourth 64-channel stretch of a staged chunk, so the D-long sums
+    // of a job -- the whole latency of a small call -- run four abreast; the partial sums meet in LDS in group order.
     constexpr int DCH = 256;  // channels staged per pass
+    constexpr int KG = 4;
     __shared__ double ys[DCTFP_MAX_N_K][DCH];
+    __shared__ double part[KG][DCTFP_MAX_N_K * DCTFP_MAX_M_K];
     __shared__ double bl[DCTFP_MAX_N_K * DCTFP_MAX_M_K];
     const int job = blockIdx.x;
     const double* __restrict__ yj = yp + (size_t)job * n * ldy;
     const int n_out = n * m;
+    const int kg = threadIdx.x >> 8, tx = threadIdx.x & 255;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int d0 = 0; d0 < n_cols; d0 += DCH) {
         const int dn = min(DCH, n_cols - d0);
         __syncthreads();
-        for (int i = threadIdx.x; i < n * DCH; i += 256) {
+        for (int i = threadIdx.x; i < n * DCH; i += 1024) {
             const int j = i / DCH, d = i % DCH;
             ys[j][d] = (d < dn) ? yj[(size_t)j * ldy + d0 + d] : 0.0;
         }
         __syncthreads();
+        const int da = kg * (DCH / KG), db = min(dn, da + DCH / KG);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int o = threadIdx.x + s * 256;
+            const int o = tx + s * 256;
             if (o < n_out) {
                 const int j = o / m, c = o % m;
-                double a = acc[s];
-                for (int d = 0; d < dn; ++d) a = fma(ys[j][d], st[(size_t)(d0 + d) * cp + c], a);
-                acc[s] = a;
+                double a0 = 0.0, a1 = 0.0;
+                int d = da;
+                for (; d + 1 < db; d += 2) {
+                    a0 = fma(ys[j][d], st[(size_t)(d0 + d) * cp + c], a0);
+                    a1 = fma(ys[j][d + 1], st[(size_t)(d0 + d + 1) * cp + c], a1);
+                }
+                if (d < db) a0 = fma(ys[j][d], st[(size_t)(d0 + d) * cp + c], a0);
+                acc[s] += a0 + a1;
             }
         }
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int o = threadIdx.x + s * 256;
-        if (o < n_out) bl[o] = acc[s];
+        const int o = tx + s * 256;
+        if (o < n_out) part[kg][o] = acc[s];
     }
     __syncthreads();
+    for (int o = threadIdx.x; o < n_out; o += 1024) bl[o] = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = wave; j < n; j += 4) {
+    for (int j = wave; j < n; j += 16) {
         double mn = INFINITY, mx = -INFINITY;
         int bad = 0;
         for (int c = lane; c < m; c += 64) {
