@@ -1396,34 +1396,118 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
     if (n_prot == 0) return DCTFP_OK;
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_TRY(hipSetDevice(ctx->device));
-    const int buf = ctx->flip;
-    Staging& stg = ctx->staging[buf];
-    DevBuf& tab = ctx->tables[buf];
-    ctx->flip ^= 1;
-    int rc = stg.ensure((size_t)n_prot * sizeof(TopkJob));
-    if (rc) return rc;
-    TopkJob* h = (TopkJob*)stg.p;
+    // long proteins (a million candidate pairs and more; a quarter of that when the call is too small to fill the chip
+    // with one workgroup per protein) are spread over many workgroups, the others get one each
+    const int64_t kLongPairs = n_prot <= 32 ? (int64_t)1 << 18 : (int64_t)1 << 20;
+    constexpr int64_t kStripePairs = (int64_t)1 << 17;
+    std::vector<int32_t> order((size_t)n_prot);
+    int32_t n_short = 0, n_long = 0;
+    int64_t n_stripes = 0;
     for (int32_t p = 0; p < n_prot; ++p) {
         const int64_t L = n_res[p];
         if (L < 0 || (L > 0 && (!maps[p] || ld[p] < L)))
             return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: protein %d: bad map", p);
-        h[p].map = (const float*)maps[p];
-        h[p].ld = ld[p];
-        h[p].n_res = (int32_t)L;
-        h[p].k = (int32_t)dctfp_contact_count((int32_t)L, t);
-        h[p].out_off = out_offs[p];
-        if (out_offs[p + 1] - out_offs[p] < h[p].k)
-            return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: protein %d: output room %lld < %d", p,
-                        (long long)(out_offs[p + 1] - out_offs[p]), h[p].k);
+        const int64_t cand = L >= 6 ? (L - 5) * (L - 4) / 2 : 0;
+        if (cand >= kLongPairs && dctfp_contact_count((int32_t)L, t) > 0) {
+            ++n_long;
+            n_stripes += std::min<int64_t>(512, (cand + kStripePairs - 1) / kStripePairs);
+        } else {
+            ++n_short;
+        }
     }
-    rc = tab.ensure((size_t)n_prot * sizeof(TopkJob));
+    {
+        int32_t a = 0, b = n_short;
+        for (int32_t p = 0; p < n_prot; ++p) {
+            const int64_t L = n_res[p];
+            const int64_t cand = L >= 6 ? (L - 5) * (L - 4) / 2 : 0;
+            if (cand >= kLongPairs && dctfp_contact_count((int32_t)L, t) > 0) order[b++] = p;
+            else order[a++] = p;
+        }
+    }
+    const size_t off_stripe = align_up((size_t)n_prot * sizeof(TopkJob), 16);
+    const size_t off_first = align_up(off_stripe + (size_t)n_stripes * sizeof(TopkStripe), 16);
+    const size_t off_state = align_up(off_first + (size_t)n_long * sizeof(int32_t), 16);
+    const size_t up_bytes = align_up(off_state + (size_t)n_long * sizeof(TopkState), 16);
+    const size_t off_ties = up_bytes;
+    const size_t all_bytes = off_ties + (size_t)n_stripes * sizeof(int32_t);
+    const int buf = ctx->flip;
+    Staging& stg = ctx->staging[buf];
+    DevBuf& tab = ctx->tables[buf];
+    ctx->flip ^= 1;
+    int rc = stg.ensure(up_bytes);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(tab.p, stg.p, (size_t)n_prot * sizeof(TopkJob), hipMemcpyHostToDevice, stream));
+    TopkJob* h = (TopkJob*)stg.p;
+    TopkStripe* hs = (TopkStripe*)((char*)stg.p + off_stripe);
+    int32_t* hfirst = (int32_t*)((char*)stg.p + off_first);
+    TopkState* hstate = (TopkState*)((char*)stg.p + off_state);
+    int64_t s_fill = 0;
+    for (int32_t q = 0; q < n_prot; ++q) {
+        const int32_t p = order[q];
+        const int64_t L = n_res[p];
+        h[q].map = (const float*)maps[p];
+        h[q].ld = ld[p];
+        h[q].n_res = (int32_t)L;
+        h[q].k = (int32_t)dctfp_contact_count((int32_t)L, t);
+        h[q].out_off = out_offs[p];
+        h[q].orig = p;
+        h[q].reserved = 0;
+        if (out_offs[p + 1] - out_offs[p] < h[q].k)
+            return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: protein %d: output room %lld < %d", p,
+                        (long long)(out_offs[p + 1] - out_offs[p]), h[q].k);
+        if (q >= n_short) {  // stripes of about equal numbers of candidate pairs (row i has L - 5 - i of them)
+            const int32_t lj = q - n_short;
+            const int64_t cand = (L - 5) * (L - 4) / 2;
+            const int64_t ns = std::min<int64_t>(512, (cand + kStripePairs - 1) / kStripePairs);
+            hfirst[lj] = (int32_t)s_fill;
+            memset(&hstate[lj], 0, sizeof(TopkState));
+            hstate[lj].need = h[q].k;
+            int64_t acc = 0;
+            int32_t row = 0, stripe = 0;
+            const int32_t last_row = (int32_t)L - 5;  // rows 0 .. L-6 have candidates
+            for (int64_t k = 0; k < ns; ++k) {
+                const int64_t goal = cand * (k + 1) / ns;
+                const int32_t begin = row;
+                while (row < last_row && (acc < goal || k + 1 == ns)) {
+                    acc += L - 5 - row;
+                    ++row;
+                }
+                if (row > begin) {
+                    TopkStripe& sp = hs[s_fill++];
+                    sp.job = lj;
+                    sp.row_begin = begin;
+                    sp.row_end = row;
+                    sp.stripe = stripe++;
+                }
+            }
+        }
+    }
+    const int64_t used_stripes = s_fill;  // (a stripe can come out empty when rows are long: it is simply not emitted)
+    rc = tab.ensure(all_bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(tab.p, stg.p, up_bytes, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(stg.ev, stream));
     stg.pending = true;
-    hipLaunchKernelGGL(contact_topk_kernel, dim3((unsigned)n_prot), dim3(1024), 0, stream, (const TopkJob*)tab.p, out_i,
-                       out_j, out_v, out_n);
-    HIP_TRY(hipGetLastError());
+    const TopkJob* djobs = (const TopkJob*)tab.p;
+    if (n_short > 0) {
+        hipLaunchKernelGGL(contact_topk_kernel, dim3((unsigned)n_short), dim3(1024), 0, stream, djobs, out_i, out_j, out_v, out_n);
+        HIP_TRY(hipGetLastError());
+    }
+    if (n_long > 0 && used_stripes > 0) {
+        const TopkJob* dlong = djobs + n_short;
+        const TopkStripe* dstripes = (const TopkStripe*)((char*)tab.p + off_stripe);
+        const int32_t* dfirst = (const int32_t*)((char*)tab.p + off_first);
+        TopkState* dstate = (TopkState*)((char*)tab.p + off_state);
+        int32_t* dties = (int32_t*)((char*)tab.p + off_ties);
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hipLaunchKernelGGL(topk_hist_kernel, dim3((unsigned)used_stripes), dim3(1024), 0, stream, dlong, dstripes, dstate, shift);
+            hipLaunchKernelGGL(topk_pick_kernel, dim3((unsigned)n_long), dim3(64), 0, stream, dlong, dstate, shift, out_n);
+        }
+        hipLaunchKernelGGL(topk_collect_kernel, dim3((unsigned)used_stripes), dim3(1024), 0, stream, dlong, dstripes, dstate, dties, out_i,
+                           out_j, out_v);
+        hipLaunchKernelGGL(topk_ties_kernel, dim3((unsigned)used_stripes), dim3(64), 0, stream, dlong, dstripes, dstate, dties, dfirst,
+                           out_i, out_j, out_v);
+        HIP_TRY(hipGetLastError());
+    }
     return mark_table_used(ctx, buf, stream);
 }
 

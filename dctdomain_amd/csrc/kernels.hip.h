@@ -1142,6 +1142,8 @@ struct TopkJob {
     int32_t n_res;
     int32_t k;
     int64_t out_off;
+    int32_t orig;  // index of the protein in the caller's arrays (out_n)
+    int32_t reserved;
 };
 
 __device__ inline uint32_t topk_key(float v) {
@@ -1168,7 +1170,7 @@ __global__ __launch_bounds__(1024) void contact_topk_kernel(const TopkJob* __res
     }
     __syncthreads();
     if (job.k <= 0 || last_row < 0) {
-        if (threadIdx.x == 0) out_n[blockIdx.x] = 0;
+        if (threadIdx.x == 0) out_n[job.orig] = 0;
         return;
     }
     for (int shift = 24; shift >= 0; shift -= 8) {
@@ -1235,7 +1237,151 @@ __global__ __launch_bounds__(1024) void contact_topk_kernel(const TopkJob* __res
             }
         }
     }
-    if (threadIdx.x == 0) out_n[blockIdx.x] = job.k;
+    if (threadIdx.x == 0) out_n[job.orig] = job.k;
+}
+
+
+// ---------------------------------------------------------------------------
+// Contact top-k of LONG proteins (L >= ~1500): the same selection, spread over many workgroups.  One workgroup per
+// (protein, stripe of rows) -- stripes hold about the same number of candidate pairs -- and one launch per step instead of
+// one workgroup walking the whole L x L map five times (13 ms for a 5 000-residue protein):
+//   4 x [ topk_hist_kernel : stripe histogram of the current radix digit  -> global histogram of the protein
+//         topk_pick_kernel : the bin that holds the k-th largest key       -> prefix / need of the next digit ]
+//   topk_collect_kernel    : everything above the threshold (and the threshold ties, if all of them are wanted) + the
+//                            number of ties per stripe
+//   topk_ties_kernel       : only if fewer ties are wanted than exist: every stripe walks its own rows in (i, j) order and
+//                            takes its ties while their global rank (ties of the earlier stripes first) is below the need --
+//                            Python's stable sort, as in contact_topk_kernel.
+// ---------------------------------------------------------------------------
+struct TopkStripe {
+    int32_t job;        // protein (index into the TopkJob array of the long proteins)
+    int32_t row_begin;  // rows [row_begin, row_end) of the map
+    int32_t row_end;
+    int32_t stripe;     // index of this stripe inside its protein
+};
+
+struct TopkState {  // per long protein, in global memory
+    uint32_t prefix;   // digits fixed so far
+    int32_t need;      // elements still wanted from the bin under the prefix
+    int32_t eq;        // elements in that bin
+    int32_t count;     // output cursor
+    int32_t hist[256];
+};
+
+__global__ __launch_bounds__(1024) void topk_hist_kernel(const TopkJob* __restrict__ jobs, const TopkStripe* __restrict__ stripes,
+                                                          TopkState* __restrict__ state, int shift) {
+    __shared__ int hist[256];
+    const TopkStripe sp = stripes[blockIdx.x];
+    const TopkJob job = jobs[sp.job];
+    const int L = job.n_res;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const uint32_t prefix = state[sp.job].prefix;
+    for (int i = sp.row_begin + wave; i < sp.row_end; i += nwaves) {
+        const float* __restrict__ row = job.map + (size_t)i * job.ld;
+        for (int j = i + 5 + lane; j < L; j += 64) {
+            const uint32_t key = topk_key(row[j]);
+            if (shift == 24 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255u], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 256; b += blockDim.x)
+        if (hist[b]) atomicAdd(&state[sp.job].hist[b], hist[b]);
+}
+
+__global__ __launch_bounds__(64) void topk_pick_kernel(const TopkJob* __restrict__ jobs, TopkState* __restrict__ state, int shift,
+                                                        int32_t* __restrict__ out_n) {
+    TopkState& st = state[blockIdx.x];
+    if (threadIdx.x == 0) {
+        if (shift == 0) out_n[jobs[blockIdx.x].orig] = jobs[blockIdx.x].k;
+        int need = st.need, b = 255;
+        for (; b > 0; --b) {
+            if (st.hist[b] >= need) break;
+            need -= st.hist[b];
+        }
+        st.prefix |= (uint32_t)b << shift;
+        st.need = need;
+        st.eq = st.hist[b];
+        for (int i = 0; i < 256; ++i) st.hist[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void topk_collect_kernel(const TopkJob* __restrict__ jobs, const TopkStripe* __restrict__ stripes,
+                                                             TopkState* __restrict__ state, int32_t* __restrict__ stripe_ties,
+                                                             int32_t* __restrict__ out_i, int32_t* __restrict__ out_j,
+                                                             float* __restrict__ out_v) {
+    __shared__ int s_ties;
+    const TopkStripe sp = stripes[blockIdx.x];
+    const TopkJob job = jobs[sp.job];
+    const int L = job.n_res;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    TopkState& st = state[sp.job];
+    const uint32_t thr = st.prefix;
+    const bool all_ties = st.eq == st.need;
+    if (threadIdx.x == 0) s_ties = 0;
+    __syncthreads();
+    int32_t* __restrict__ oi = out_i + job.out_off;
+    int32_t* __restrict__ oj = out_j + job.out_off;
+    float* __restrict__ ov = out_v + job.out_off;
+    int my_ties = 0;
+    for (int i = sp.row_begin + wave; i < sp.row_end; i += nwaves) {
+        const float* __restrict__ row = job.map + (size_t)i * job.ld;
+        for (int j = i + 5 + lane; j < L; j += 64) {
+            const float v = row[j];
+            const uint32_t key = topk_key(v);
+            if (key > thr || (all_ties && key == thr)) {
+                const int pos = atomicAdd(&st.count, 1);
+                oi[pos] = i;
+                oj[pos] = j;
+                ov[pos] = v;
+            } else if (key == thr) {
+                ++my_ties;
+            }
+        }
+    }
+    if (my_ties) atomicAdd(&s_ties, my_ties);
+    __syncthreads();
+    if (threadIdx.x == 0) stripe_ties[blockIdx.x] = s_ties;
+}
+
+// grid = stripes; `first_stripe[job]` = index of the protein's first stripe.  Runs after topk_collect_kernel has finished.
+__global__ __launch_bounds__(64) void topk_ties_kernel(const TopkJob* __restrict__ jobs, const TopkStripe* __restrict__ stripes,
+                                                        const TopkState* __restrict__ state, const int32_t* __restrict__ stripe_ties,
+                                                        const int32_t* __restrict__ first_stripe, int32_t* __restrict__ out_i,
+                                                        int32_t* __restrict__ out_j, float* __restrict__ out_v) {
+    const TopkStripe sp = stripes[blockIdx.x];
+    const TopkJob job = jobs[sp.job];
+    const TopkState& st = state[sp.job];
+    if (st.eq == st.need) return;  // every tie was wanted and has been collected
+    const int need_eq = st.need;
+    const int L = job.n_res;
+    const int lane = threadIdx.x;
+    int before = 0;  // ties in the earlier stripes of this protein
+    for (int s = first_stripe[sp.job]; s < (int)blockIdx.x; ++s) before += stripe_ties[s];
+    if (before >= need_eq) return;
+    const uint32_t thr = st.prefix;
+    const int base = job.k - need_eq;  // the elements above the threshold fill the front of the output
+    int32_t* __restrict__ oi = out_i + job.out_off;
+    int32_t* __restrict__ oj = out_j + job.out_off;
+    float* __restrict__ ov = out_v + job.out_off;
+    int taken = before;
+    for (int i = sp.row_begin; i < sp.row_end && taken < need_eq; ++i) {
+        const float* __restrict__ row = job.map + (size_t)i * job.ld;
+        for (int j0 = i + 5; j0 < L && taken < need_eq; j0 += 64) {
+            const int j = j0 + lane;
+            const float v = (j < L) ? row[j] : 0.0f;
+            const bool hit = (j < L) && topk_key(v) == thr;
+            const unsigned long long mk = __ballot(hit);
+            const int rank = taken + __popcll(mk & ((1ull << lane) - 1ull));
+            if (hit && rank < need_eq) {
+                oi[base + rank] = i;
+                oj[base + rank] = j;
+                ov[base + rank] = v;
+            }
+            taken += __popcll(mk);
+        }
+    }
 }
 
 

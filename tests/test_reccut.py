@@ -161,7 +161,9 @@ def test_gpu_topk_batch_mixed_lengths():
     import torch
     from dctdomain_amd import reccut
     maps = [make_contacts(r, L, 900 + i) for i, (r, L) in enumerate(
-        [('blocks', 3), ('ties', 77), ('sparse', 640), ('flat', 50), ('blocks', 1035), ('negzero', 64), ('blocks', 6)])]
+        [('blocks', 3), ('ties', 77), ('sparse', 640), ('flat', 50), ('blocks', 1035), ('negzero', 64), ('blocks', 6),
+         # long proteins: a million candidate pairs and more go through the multi-workgroup selection
+         ('blocks', 1700), ('flat', 1500), ('sparse', 2300), ('ties', 1601), ('negzero', 1460), ('blocks', 40)])]
     offs, ci, cj, cv = reccut.top_contacts_batch([torch.from_numpy(m).cuda() for m in maps], 2.6)
     for p, m in enumerate(maps):
         oi, oj, ov = co.top_contacts(m, 2.6)

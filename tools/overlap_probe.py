@@ -1,7 +1,6 @@
 """(Every config list runs twice per case, ABAB: the first config after a table change is ~1 % slower.)
-Does stage B really run under stage A?  Same embeddings (8000 x 500 x 1280, 2 layers), domain lists with a
-growing number of fingerprints per byte; sweeps the stage-A launch shape and an LDS pad that caps the stage-A
-workgroups per CU so that one stage-B workgroup always finds room (option a_lds_pad)."""
+Two-kernel path (option path = 1): does stage B really run under stage A?  Same embeddings (8000 x 500 x 1280, 2 layers),
+domain lists with a growing number of fingerprints per byte; sweeps the stage-A launch shape and the overlap depth."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -20,7 +19,8 @@ cases = {'whole only (C2)': [f'1-{L}'], '5 parts + whole': parts(5) + [f'1-{L}']
 workload = None
 if len(sys.argv) > 1 and sys.argv[1] in ('c4', 'c5'):     # the bench.py mixes instead of the synthetic cases
     workload = sys.argv.pop(1)
-configs = [tuple(int(v) for v in (c + ',0,0,4096').split(',')[:6]) for c in sys.argv[1:]] or [(0, 0, 4, 0, 0, 4096)]     # (a_waves, a_lds_pad, overlap, b_variant, a_alt, workspace_mb)
+configs = [tuple(int(v) for v in (c + ',4,4096').split(',')[:3]) for c in sys.argv[1:]] or [(0, 4, 4096)]     # (a_waves, overlap, workspace_mb)
+ctx.set_option('path', 1)
 nbytes = 2 * n_seq * L * D * 4
 tables = {name: dd.PieceTable([L] * n_seq, [doms] * n_seq) for name, doms in cases.items()}
 if workload:
@@ -39,9 +39,9 @@ if workload:
 for name, table in tables.items():
     out = torch.empty((table.n_domains, 480), dtype=torch.int8, device=dev)
     ref = None
-    for waves, pad, ov, bv, alt, ws in configs + configs:
-        ctx.set_option('a_alt', alt); ctx.set_option('workspace_mb', ws)
-        ctx.set_option('a_waves', waves); ctx.set_option('a_lds_pad', pad); ctx.set_option('overlap', ov); ctx.set_option('b_variant', bv)
+    for waves, ov, ws in configs + configs:
+        ctx.set_option('workspace_mb', ws)
+        ctx.set_option('a_waves', waves); ctx.set_option('overlap', ov)
         for _ in range(3):
             dd.quantize_batch(lbs, table, out=out, ctx=ctx)
         ctx.set_option('profile', 1); ctx.profile()
@@ -52,6 +52,6 @@ for name, table in tables.items():
         ms, nl = ctx.profile(); ctx.set_option('profile', 0)
         if ref is None: ref = out.clone()
         same = bool((ref == out).all())
-        print(f'{name:20s} waves {waves} pad {pad:5d} overlap {ov} B{bv} alt{alt} ws{ws}: step {1e3 * dt:7.3f} ms = {nbytes / dt / 1e9:5.0f} GB/s   '
+        print(f'{name:20s} waves {waves} overlap {ov} ws{ws}: step {1e3 * dt:7.3f} ms = {nbytes / dt / 1e9:5.0f} GB/s   '
               f'A sum {ms[0] / 10:7.3f} ms  B sum {ms[1] / 10:6.3f} ms  same={same}', flush=True)
-ctx.set_option('a_waves', 0); ctx.set_option('a_lds_pad', 0); ctx.set_option('overlap', 4); ctx.set_option('b_variant', 0); ctx.set_option('a_alt', 0); ctx.set_option('workspace_mb', 4096)
+ctx.set_option('a_waves', 0); ctx.set_option('overlap', 4); ctx.set_option('workspace_mb', 4096); ctx.set_option('path', 0)
