@@ -522,6 +522,7 @@ void launch_walk_impl(const WParams& p, bool fused) {
 template <int S, int G>
 int launch_walk_u(const WParams& p, int unroll, bool fused) {
     if (unroll == 4) launch_walk_impl<S, G, 5, 4>(p, fused);
+    else if (unroll == 6) launch_walk_impl<S, G, 5, 6>(p, fused);
     else launch_walk_impl<S, G, 5, 8>(p, fused);
     return DCTFP_OK;
 }
@@ -658,7 +659,7 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         if (value != 0 && (value < 2 || value > 4)) return fail(DCTFP_ERR_INVALID, "ab_group must be 0 (auto) or 2..4 jobs per flush");
         ctx->opt_ab_group = value;
     } else if (n == "ab_unroll") {
-        if (value != 0 && value != 4 && value != 8) return fail(DCTFP_ERR_INVALID, "ab_unroll must be 0 (auto), 4 or 8");
+        if (value != 0 && value != 4 && value != 6 && value != 8) return fail(DCTFP_ERR_INVALID, "ab_unroll must be 0 (auto), 4, 6 or 8");
         ctx->opt_ab_unroll = value;
     } else if (n == "ab_run_jobs") {
         if (value < 0 || value > 4096) return fail(DCTFP_ERR_INVALID, "ab_run_jobs must be 0 (auto) .. 4096");
@@ -965,7 +966,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         if (use_walk) {
             walk_s = g.n_cols <= 768 ? 3 : (g.n_cols <= 1280 ? 5 : 10);
             // jobs per flush: 4 leaves LDS for 17 waves per CU; fused walks keep two more accumulator sets alive across a
-            // flush and only fit their registers with 3 (and 4 rows in flight instead of 8)
+            // flush and only fit their registers with 3 (and 6 rows in flight instead of 8: 8 spills, 4 is 2-3 % slower)
             walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : ((walk_s == 10 || fuse) ? 3 : 4);
             for (int64_t j = 0; j < n_jobs;) {
                 const int64_t d = j % n_domains;
@@ -1178,7 +1179,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             wp.degenerate = ctx->degenerate;
             wp.grid = (unsigned)n_runs;
             wp.stream = stream;
-            rc = launch_walk(wp, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : (fuse ? 4 : 8), fuse);
+            rc = launch_walk(wp, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : (fuse ? 6 : 8), fuse);
             if (rc) return rc;
             HIP_TRY(hipGetLastError());
             rc = prof_end(ep, stream);

@@ -58,10 +58,10 @@ SUBSET = [c for c in ALL_OK if c['id'].startswith(('two_', 'dom_', 'qdim_', 'con
 @pytest.mark.parametrize('opts', [dict(stage_b=0), dict(stage_b=1), dict(a_waves=8, a_unroll=4),
                                   dict(a_waves=16, a_unroll=8), dict(a_waves=4, a_unroll=4),
                                   dict(workspace_mb=16), dict(a_waves=2, a_unroll=8), dict(a_waves=1), dict(overlap=1), dict(fuse=0), dict(pack_y=0),
-                                  dict(path=1), dict(path=1, fuse=0), dict(ab_unroll=4), dict(ab_unroll=8), dict(ab_group=3), dict(ab_group=4), dict(path=2), dict(ab_run_jobs=4), dict(ab_run_jobs=64),
+                                  dict(path=1), dict(path=1, fuse=0), dict(ab_unroll=4), dict(ab_unroll=6), dict(ab_unroll=8), dict(ab_group=3), dict(ab_group=4), dict(path=2), dict(ab_run_jobs=4), dict(ab_run_jobs=64),
                                   dict(ab_run_jobs=1)],
                          ids=['valuB', 'mfmaB', 'w8u4', 'w16u8', 'w4u4', 'smallws', 'w2u8', 'w1', 'nooverlap', 'nofuse', 'nopack',
-                              'twokernels', 'twokernels_nofuse', 'walk_u4', 'walk_u8', 'walk_g3', 'walk_g4', 'walk_forced', 'walk_run4', 'walk_run64', 'walk_run1'])
+                              'twokernels', 'twokernels_nofuse', 'walk_u4', 'walk_u6', 'walk_u8', 'walk_g3', 'walk_g4', 'walk_forced', 'walk_run4', 'walk_run64', 'walk_run1'])
 def test_kernel_variants_agree_with_golden(dd, opts):
     import torch
     ctx = dd.get_context(torch.cuda.current_device())
