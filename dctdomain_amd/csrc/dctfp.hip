@@ -965,9 +965,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         int walk_s = 0, walk_g = 0;
         if (use_walk) {
             walk_s = g.n_cols <= 768 ? 3 : (g.n_cols <= 1280 ? 5 : 10);
-            // jobs per flush: 4 leaves LDS for 17 waves per CU; fused walks keep two more accumulator sets alive across a
-            // flush and only fit their registers with 3 (and 6 rows in flight instead of 8: 8 spills, 4 is 2-3 % slower)
-            walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : ((walk_s == 10 || fuse) ? 3 : 4);
+            // jobs per flush: 4 leaves LDS for 17 waves per CU (S = 10: 3, so that two workgroups fit)
+            walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : (walk_s == 10 ? 3 : 4);
             for (int64_t j = 0; j < n_jobs;) {
                 const int64_t d = j % n_domains;
                 Walk& wk = hwalk[n_walks++];
@@ -1179,7 +1178,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             wp.degenerate = ctx->degenerate;
             wp.grid = (unsigned)n_runs;
             wp.stream = stream;
-            rc = launch_walk(wp, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : (fuse ? 6 : 8), fuse);
+            rc = launch_walk(wp, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : 8, fuse);
             if (rc) return rc;
             HIP_TRY(hipGetLastError());
             rc = prof_end(ep, stream);

@@ -367,8 +367,10 @@ __global__ __launch_bounds__(WAVES * 64, (FUSED && N == 3 && VEC == 4 && UNROLL 
             for (int v = 0; v < VEC; ++v) ref[v] = raw_elem<T, VEC>(r0, v);
         }
 
-        for (uint32_t p = 0; p < job.n_pieces; ++p) {
-            const PieceA piece = pc[p];
+        // (the test of `has_w` stays outside the row loops: a branch per row would pin the whole protein's cosine load next to
+        //  its use and expose its latency row after row)
+        auto stream_piece = [&](auto hw_tag, const PieceA& piece) {
+            constexpr bool HW = decltype(hw_tag)::value;
             const T* __restrict__ base = reinterpret_cast<const T*>(piece.ptr) + colc;
             const CosTab btp = bt + (size_t)piece.t0 * NK;
             const CosTab wtp = wt + (size_t)piece.w0 * NK;
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(WAVES * 64, (FUSED && N == 3 && VEC == 4 && UNROLL 
 #pragma unroll
                     for (int k = 0; k < NK; ++k) acc[k][v] = fma(c[k], d, acc[k][v]);
                 }
-                if (FUSED && has_w) {
+                if constexpr (HW) {
                     const CosTab cw = wtp + (size_t)r * NK;
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
@@ -403,6 +405,11 @@ __global__ __launch_bounds__(WAVES * 64, (FUSED && N == 3 && VEC == 4 && UNROLL 
                 auto x1 = load_raw<T, VEC>(base + (size_t)r * ld);
                 row_update(x1, r);
             }
+        };
+        for (uint32_t p = 0; p < job.n_pieces; ++p) {
+            const PieceA piece = pc[p];
+            if (FUSED && has_w) stream_piece(std::integral_constant<bool, FUSED>{}, piece);
+            else stream_piece(std::false_type{}, piece);
         }
         finish_job(acc, job_id, part == 0);
     }
@@ -839,8 +846,11 @@ __global__ __launch_bounds__(S * 64, 4) void walk_ab_kernel(const JobA* __restri
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) ref[v] = (double)r0[v];
                 }
-                for (uint32_t p = 0; p < job.n_pieces; ++p) {
-                    const PieceA piece = pc[p];
+                // The stream of one piece, once with and once without the whole-protein accumulation: the test of `has_w`
+                // must not sit inside the row loop -- a branch per row keeps the whole protein's cosine load (s_load) next
+                // to its use, its latency exposed row after row (that was 20 % of the fused walks).
+                auto stream_piece = [&](auto hw_tag, const PieceA& piece) {
+                    constexpr bool HW = decltype(hw_tag)::value;
                     const float* __restrict__ base = reinterpret_cast<const float*>(piece.ptr) + colc;
                     const CosTab btp = cos_tab(job.basis) + (size_t)piece.t0 * NK;
                     const CosTab wtp = cos_tab(job.w_basis) + (size_t)piece.w0 * NK;
@@ -852,7 +862,7 @@ __global__ __launch_bounds__(S * 64, 4) void walk_ab_kernel(const JobA* __restri
 #pragma unroll
                             for (int k = 0; k < NK; ++k) f[k][v] = fma(c[k], d, f[k][v]);
                         }
-                        if (FUSED && has_w) {
+                        if constexpr (HW) {
                             const CosTab cw = wtp + (size_t)r * NK;
 #pragma unroll
                             for (int v = 0; v < VEC; ++v) {
@@ -868,10 +878,7 @@ __global__ __launch_bounds__(S * 64, 4) void walk_ab_kernel(const JobA* __restri
 #pragma unroll
                         for (int u = 0; u < UNROLL; ++u) xv[u] = load_raw<float, VEC>(base + (size_t)(r + u) * ld);
 #pragma unroll
-                        for (int u = 0; u < UNROLL; ++u) {
-                            row_update(xv[u], r + u);
-                            if constexpr (FUSED) __builtin_amdgcn_sched_barrier(0);  // row by row: the fused variant has no registers for more
-                        }
+                        for (int u = 0; u < UNROLL; ++u) row_update(xv[u], r + u);
                     }
                     if constexpr (UNROLL > 4) {  // what is left of the piece: a group of 4 ...
                         if (r + 4 <= piece.n_rows) {
@@ -892,6 +899,11 @@ __global__ __launch_bounds__(S * 64, 4) void walk_ab_kernel(const JobA* __restri
                         for (int u = 0; u < 3; ++u)
                             if (r + u < piece.n_rows) row_update(xv[u], r + u);
                     }
+                };
+                for (uint32_t p = 0; p < job.n_pieces; ++p) {
+                    const PieceA piece = pc[p];
+                    if (FUSED && has_w) stream_piece(std::integral_constant<bool, FUSED>{}, piece);
+                    else stream_piece(std::false_type{}, piece);
                 }
             } else {
 #pragma unroll

@@ -187,7 +187,7 @@ int dctfp_host_device_pointer(void* host, void** dev);
  *                  1 = always the two-kernel path; 2 = the walk kernel wherever its shapes allow (also D <= 2560)
  *   "last_path"    read only: which kernels the last dctfp_quantize launched (1 = two kernels, 2 = walk kernel)
  *   "ab_group"     walk kernel: jobs per stage-B flush (0 = by shape, 2..4)
- *   "ab_unroll"    walk kernel: rows in flight per wave (0 = by shape: 8, fused walks 6; 4, 6, 8)
+ *   "ab_unroll"    walk kernel: rows in flight per wave (0 = 8; 4, 6, 8)
  *   "ab_run_jobs"  walk kernel: jobs per workgroup (0 = by batch size)
  *   "stage_b"      two-kernel path: 0 = plain VALU stage B, 1 = MFMA f64 kernel (default)
  *   "a_waves"      two-kernel path: waves per stage-A workgroup: 0 = by average rows per job (default), 2, 4, 8, 16
