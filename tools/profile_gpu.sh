@@ -5,6 +5,7 @@ set -o pipefail
 TAG=${1:-r01}; shift
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf "$OUT"   # (results of an earlier run would be averaged into the summary)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
