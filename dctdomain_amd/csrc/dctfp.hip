@@ -139,7 +139,7 @@ struct Staging {  // pinned host buffer + the event after its last H2D copy (or 
 
 struct StEntry {  // stage-B basis  St[d][c] (ldy x cp), zero padded
     double* dev = nullptr;
-    double* frag = nullptr;  // the same values in MFMA-fragment order (walk_ab_kernel), `frag_groups` 16-channel groups
+    double* frag = nullptr;  // even/odd halves of the basis in MFMA-fragment order (walk_ab_kernel), `frag_groups` 16-pair groups
     int frag_groups = 0;
     int ldy = 0, cp = 0;
     uint64_t last_use = 0;
@@ -298,17 +298,35 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
         (void)hipFree(e.dev);
         return fail(DCTFP_ERR_HIP, "hipMemcpy(St): %s", hipGetErrorString(err));
     }
-    if (cp <= 80) {
-        // fragment order for walk_ab_kernel: frag[((q * 4 + r) * NT + c) * 64 + lane] = St[16 q + 4 (lane >> 4) + r][16 c + (lane & 15)]
-        const int nt = cp / 16;
-        e.frag_groups = (n_cols + 15) / 16;
+    if (cp == 80 && n_cols % 4 == 0) {
+        // walk_ab_kernel contracts the even and the odd half of the basis apart (kernels.hip.h, "flush"):
+        //   E[d][c] = sum over even k, O[d][c] = sum over odd k of cos_m(k, c) cos_D(k, d),  d < D/2, c < ceil(m/2)
+        // Tab[d] = [E[d][0..39] | O[d][0..39]] (zero past ceil(m/2); odd m: O is exactly 0 in the middle column), in
+        // fragment order: frag[((q * 4 + r) * 5 + c) * 64 + lane] = Tab[16 q + 4 (lane >> 4) + r][16 c + (lane & 15)]
+        const int nt = 5, half = n_cols / 2, hm = (m + 1) / 2;
+        e.frag_groups = (half + 15) / 16;
+        std::vector<double> tab((size_t)half * 80, 0.0);
+        std::vector<long double> ce(hm), co(hm);
+        for (int d = 0; d < half; ++d) {
+            for (int c = 0; c < hm; ++c) ce[c] = co[c] = 0.0L;
+            for (int k = 1; k < m; ++k) {
+                const long double b = cb[(size_t)k * n_cols + d];
+                const long double* a = &ca[(size_t)k * m];
+                long double* dst = (k & 1) ? co.data() : ce.data();
+                for (int c = 0; c < hm; ++c) dst[c] += a[c] * b;
+            }
+            for (int c = 0; c < hm; ++c) {
+                tab[(size_t)d * 80 + c] = (double)ce[c];
+                tab[(size_t)d * 80 + 40 + c] = (m - 1 - c == c) ? 0.0 : (double)co[c];
+            }
+        }
         std::vector<double> fr((size_t)e.frag_groups * nt * 256, 0.0);
         for (int q = 0; q < e.frag_groups; ++q)
             for (int r = 0; r < 4; ++r)
                 for (int c = 0; c < nt; ++c)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int d = 16 * q + 4 * (lane >> 4) + r, col = 16 * c + (lane & 15);
-                        if (d < n_cols) fr[(((size_t)q * 4 + r) * nt + c) * 64 + lane] = host[(size_t)d * cp + col];
+                        if (d < half) fr[(((size_t)q * 4 + r) * nt + c) * 64 + lane] = tab[(size_t)d * 80 + col];
                     }
         err = hipMalloc((void**)&e.frag, fr.size() * sizeof(double));
         if (err == hipSuccess) err = hipMemcpy(e.frag, fr.data(), fr.size() * sizeof(double), hipMemcpyHostToDevice);
@@ -955,11 +973,11 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         // (a wave streams all rows of its channels).  Everything else runs stage A -> Y' -> stage B.
         const bool walk_ok = !trivial && n == 3 && m > 64 && m <= 80 && g.dtype == DCTFP_F32 && vec == 4 && g.n_cols >= 512 &&
                              g.n_cols <= 2560 && max_len_all <= 8192 && ctx->opt_stage_b == 1;
-        // Measured (profiles/r02): the walk kernel wins at D <= 1280 (3 or 5 waves per workgroup); at D = 2560 its 10-wave
-        // workgroups leave one workgroup per CU and the two-kernel path is 4 % faster -- "auto" keeps that one there.
+        // Measured (profiles/r02): the walk kernel wins at every width it takes -- D = 2560 (10-wave workgroups, one per CU)
+        // since its flush contracts the even and odd halves of the basis apart: 5.3 against 4.9-5.25 TB/s on config 4.
         // A small call (a protein at a time, the reference's calling pattern) is latency-bound: there the two-kernel path,
         // which spreads one job over slabs x 8 waves, finishes first.
-        const bool use_walk = walk_ok && (ctx->opt_path == 2 || (ctx->opt_path == 0 && g.n_cols <= 1280 && n_jobs >= 512));
+        const bool use_walk = walk_ok && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 512));
         // walks of ALL jobs (walk kernel) -- the two-kernel path builds its walks per chunk below
         int64_t n_walks = 0, n_runs = 0;
         int walk_s = 0, walk_g = 0;

@@ -787,8 +787,16 @@ struct Run {
 
 constexpr int kWalkChannels = 256;  // channels per wave: 64 lanes x 4 float32
 
+// Build-time knobs of the walk kernel (A/B builds: tools/build_variant.sh).
+#ifndef DCTFP_WALK_MIN_WAVES
+#define DCTFP_WALK_MIN_WAVES 4       // waves per SIMD the register allocation is held to (4 -> 128 VGPRs)
+#endif
+#ifndef DCTFP_WALK_B_DEPTH
+#define DCTFP_WALK_B_DEPTH 1         // k-steps of stage-B fragments in flight during a flush (1, 2, 4); more was never faster:
+#endif                               // what a flush costs is issue time, not L2 latency (profiles/r02/experiments/flush_*)
+
 template <int S, int G, int NT, int UNROLL, bool FUSED>
-__global__ __launch_bounds__(S * 64, 4) void walk_ab_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
+__global__ __launch_bounds__(S * 64, DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
                                                           const Walk* __restrict__ walks, const Run* __restrict__ runs,
                                                           const PieceA* __restrict__ pieces, const double* __restrict__ stf,
                                                           int8_t* __restrict__ out, int n_cols, int64_t ld, int m,
@@ -802,11 +810,19 @@ __global__ __launch_bounds__(S * 64, 4) void walk_ab_kernel(const JobA* __restri
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const Run run = runs[blockIdx.x];
-    const int col0 = (wave * 64 + lane) * VEC;
-    const bool pad = col0 >= n_cols;
-    const int colc = pad ? 0 : col0;  // out-of-range lanes stream column 0 and are discarded
-    // 16-channel groups of this wave that hold real channels
-    const int n_q = min(16, max(0, (n_cols + 15) / 16 - wave * 16));
+    // A wave owns 128 channel pairs (d, D-1-d): lanes 0..31 stream channels [128 w, 128 w + 128), lanes 32..63 their mirror
+    // images -- two 512-byte segments of every row (as fast as one of 1 KiB: tools/microbench/read_ceiling.hip) -- so that
+    // the even/odd fold of the flush finds both channels of a pair in the wave's own slots.
+    const int half = n_cols >> 1;
+    const int pair0 = wave * (kWalkChannels / 2) + VEC * (lane & 31);  // the first of my 4 pairs
+    const bool mirror = lane >= 32;
+    const bool pad = pair0 >= half;  // out-of-range lanes stream column 0 and are discarded
+    const int colc = pad ? 0 : (mirror ? n_cols - VEC - pair0 : pair0);
+    // D % 8 == 4: the last 4 channels before D/2 are 2 pairs; both lanes that read them hold all four Y', the flush takes
+    // each pair once -- and the degenerate-channel counter must see each channel once
+    auto channel_counts = [&](int v) { return !pad && pair0 + (mirror ? VEC - 1 - v : v) < half; };
+    // 16-pair groups of this wave that hold real pairs
+    const int n_q = min(kWalkChannels / 32, max(0, (half + 15) / 16 - wave * (kWalkChannels / 32)));
     typedef v4f Rw;
 
     uint32_t pending = 0;            // jobs whose Y' sits in LDS
@@ -921,7 +937,7 @@ __global__ __launch_bounds__(S * 64, 4) void walk_ab_kernel(const JobA* __restri
                     const double fk[NK] = {f[0][v], f[1][v]};
                     double t;
                     unsigned code;
-                    scale_pack3(fk, inv, pad, t, code, degenerate);
+                    scale_pack3(fk, inv, !channel_counts(v), t, code, degenerate);
                     t4[v] = t;
                     c4 |= code << (8 * v);
                     __builtin_amdgcn_sched_barrier(0);  // one channel at a time (register pressure)
@@ -934,50 +950,70 @@ __global__ __launch_bounds__(S * 64, 4) void walk_ab_kernel(const JobA* __restri
             if (pending < (uint32_t)G && !last) continue;
 
             // ---- flush: stage B of the `pending` jobs in LDS (P = pending as a compile-time count)
+            // Both cosine factors of St[d][c] = sum_k cos_m(k, c) cos_D(k, d) are mirror (anti)symmetric:
+            //   St[d][c] = E[d][c] + O[d][c],  St[D-1-d][c] = St[d][m-1-c] = E[d][c] - O[d][c]     (E: even k, O: odd k)
+            // so with u = y[d] + y[D-1-d], v = y[d] - y[D-1-d] over the D/2 channel pairs and the m/2 left columns
+            //   ZE[c] = sum_d u_d E[d][c],  ZO[c] = sum_d v_d O[d][c],  Z[c] = ZE[c] + ZO[c],  Z[m-1-c] = ZE[c] - ZO[c]
+            // -- half the multiply-adds of the plain product.  The MFMAs of a flush are issue time the stream does not get
+            // (tools/microbench/f64_pipes.hip): on 70..110-row jobs they were 17 % (D = 2560) of the kernel.
+            // The table (`stf`, host: get_st) holds [E | O] in fragment order: 80 slots = E columns 0..39, O columns 0..39.
+            // Both channels of a pair sit in the wave's own slot: entries 0..127 the channels d, 128..255 their mirrors in
+            // ascending channel order (pair p of the wave <-> entries p and 128 + (p ^ 3)).
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             auto contract = [&](auto p_const) {
                 constexpr int P = decltype(p_const)::value;
+                static_assert(NT == 5, "slots 0..39 = E, 40..79 = O: the middle column group is half and half");
                 const int g4 = lane >> 4, row = lane & 3;
+                const bool odd_half = (lane & 8) != 0;  // blocks 2, 3 of the middle column group belong to O
                 double acc[P][NT];
 #pragma unroll
                 for (int g = 0; g < P; ++g)
 #pragma unroll
                     for (int c = 0; c < NT; ++c) acc[g][c] = 0.0;
-                // B fragments of k-step (q, r): NT column groups x 8 bytes per lane, fetched one k-step ahead
-                const double* __restrict__ sq = stf + (size_t)wave * 16 * 4 * NT * 64 + lane;
+                // B fragments of k-step (q, r): NT column groups x 8 bytes per lane
+                const double* __restrict__ sq = stf + (size_t)wave * (kWalkChannels / 32) * 4 * NT * 64 + lane;
                 auto fetch_b = [&](double (&b)[NT], int step) {
 #pragma unroll
                     for (int c = 0; c < NT; ++c) b[c] = sq[((size_t)step * NT + c) * 64];
                 };
-                constexpr bool AHEAD = !FUSED;  // the fused variant has no registers to spare for a second operand set
-                double bq[AHEAD ? 2 : 1][NT];
-                if (AHEAD && n_q > 0) fetch_b(bq[0], 0);
-                for (int q = 0; q < n_q; ++q) {
-                    uint32_t c4[P];
+                // DEPTH k-steps of fragments are in flight ahead of their use: a slot is refilled for step + DEPTH right after
+                // its MFMAs.  Past the end the last step is fetched again (no branch, static vmcnt).
+                constexpr int DEPTH = DCTFP_WALK_B_DEPTH;
+                static_assert(DEPTH == 1 || DEPTH == 2 || DEPTH == 4, "slot of a k-step must be static under the 4-step unroll");
+                double bq[DEPTH][NT];
+                const int last_step = 4 * n_q - 1;
+                if (n_q > 0) {
 #pragma unroll
-                    for (int g = 0; g < P; ++g) c4[g] = lds_c[wave][g][4 * q + g4];
+                    for (int r = 0; r < DEPTH; ++r) fetch_b(bq[r], r);
+                }
+                for (int qi = 0; qi < n_q; ++qi) {
+                    const int pl0 = 16 * qi + 4 * g4;  // my pairs of this group: pl0 + r
+                    const int p0 = wave * (kWalkChannels / 2) + pl0;
+                    uint32_t c4[P], c4m[P];
+#pragma unroll
+                    for (int g = 0; g < P; ++g) {
+                        c4[g] = lds_c[wave][g][pl0 >> 2];
+                        c4m[g] = lds_c[wave][g][32 + (pl0 >> 2)];
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int step = 4 * q + r;
-                        if constexpr (AHEAD) {
-                            if (step + 1 < 4 * n_q) fetch_b(bq[(r + 1) & 1], step + 1);
-                        } else {
-                            fetch_b(bq[0], step);
+                        const bool live = p0 + r < half;  // pairs past D/2 (D % 32 != 0): zero, whatever the slots hold
+#pragma unroll
+                        for (int g = 0; g < P; ++g) {
+                            const double y = unpack_y((c4[g] >> (8 * r + 2 * row)) & 3u, lds_t[wave][g][pl0 + r]);
+                            const double ym = unpack_y((c4m[g] >> (8 * (3 - r) + 2 * row)) & 3u, lds_t[wave][g][128 + pl0 + 3 - r]);
+                            const double au = live ? y + ym : 0.0, av = live ? y - ym : 0.0;
+                            const double ax = odd_half ? av : au;
+                            // NT * P independent accumulators between two uses of one
+#pragma unroll
+                            for (int c = 0; c < NT; ++c)
+                                acc[g][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(c < 2 ? au : (c == 2 ? ax : av), bq[r % DEPTH][c], acc[g][c], 0, 0, 0);
                         }
-                        double a[P];
-#pragma unroll
-                        for (int g = 0; g < P; ++g)
-                            a[g] = unpack_y((c4[g] >> (8 * r + 2 * row)) & 3u, lds_t[wave][g][16 * q + 4 * g4 + r]);
-                        // NT * P independent accumulators between two uses of one
-#pragma unroll
-                        for (int c = 0; c < NT; ++c)
-#pragma unroll
-                            for (int g = 0; g < P; ++g)
-                                acc[g][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g], bq[AHEAD ? (r & 1) : 0][c], acc[g][c], 0, 0, 0);
+                        fetch_b(bq[r % DEPTH], min(4 * qi + r + DEPTH, last_step));
                     }
                 }
-                // partial blocks -> my slots (the Y' in them is consumed): zp[row][col], rows 0..2 = lanes 0..47
+                // partial blocks -> my slots (the Y' in them is consumed): zp[row][slot], rows 0..2 = lanes 0..47
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 48) {
 #pragma unroll
@@ -994,21 +1030,24 @@ __global__ __launch_bounds__(S * 64, 4) void walk_ab_kernel(const JobA* __restri
                 default: if constexpr (G >= 4) contract(std::integral_constant<int, 4>{}); break;
             }
             __syncthreads();
-            // sum over the waves in wave order, per-row min-max scale, int8 (src/fingerprint.py:193-195)
+            // sum over the waves in wave order, Z[c] = ZE[c] + ZO[c] and Z[m-1-c] = ZE[c] - ZO[c], per-row min-max scale, int8
+            // (src/fingerprint.py:193-195); lane c < ceil(m / 2) holds both
+            const int hm = (m + 1) >> 1;
             for (uint32_t idx = (uint32_t)wave; idx < pending * 3u; idx += S) {
                 const uint32_t g = idx / 3u, j = idx - 3u * g;
-                double v[2];
+                double v[2] = {0.0, 0.0};
                 bool valid[2];
+                valid[0] = lane < hm;
+                valid[1] = lane < hm && (m - 1 - lane) != lane;  // odd m: the middle column is its own mirror (O = 0 there)
+                if (valid[0]) {
+                    double ze = 0.0, zo = 0.0;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int col = lane + 64 * h;
-                    valid[h] = col < m;
-                    double sum = 0.0;
-                    if (valid[h]) {
-#pragma unroll
-                        for (int w = 0; w < S; ++w) sum += lds_t[w][g][j * (NT * 16) + col];
+                    for (int w = 0; w < S; ++w) {
+                        ze += lds_t[w][g][j * (NT * 16) + lane];
+                        zo += lds_t[w][g][j * (NT * 16) + 40 + lane];
                     }
-                    v[h] = sum;
+                    v[0] = ze + zo;
+                    v[1] = ze - zo;
                 }
                 double mn = INFINITY, mx = -INFINITY;
                 int bad = 0;
@@ -1027,9 +1066,8 @@ __global__ __launch_bounds__(S * 64, 4) void walk_ab_kernel(const JobA* __restri
                 }
                 int8_t* __restrict__ o = out + jobb[group_job + g].out_off + (int64_t)j * m;
                 const double den = mx - mn;
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    if (valid[h]) o[lane + 64 * h] = quant127(v[h] - mn, den, bad != 0);
+                if (valid[0]) o[lane] = quant127(v[0] - mn, den, bad != 0);
+                if (valid[1]) o[m - 1 - lane] = quant127(v[1] - mn, den, bad != 0);
             }
             __syncthreads();  // the slots are free again
             group_job += pending;

@@ -570,3 +570,52 @@ def test_config4_batch_with_reference_goldens_inside(dd):
     np.testing.assert_array_equal(plain, out)
     rows = out.reshape(-1, 6, 80)
     assert ((rows == 127).sum(axis=2) == 1).all() and ((rows == 0).sum(axis=2) >= 1).all()
+
+
+def test_walk_kernel_widths_and_kept_columns_against_oracle(dd):
+    """The walk kernel contracts stage B in even/odd halves over channel pairs (d, D-1-d) and column pairs (c, m-1-c):
+    widths where D/2 is not a multiple of 4 (D % 8 == 4: two lanes hold the same four channels) or of 16 (zero-padded
+    pair groups), odd m (the middle column is its own mirror) and every wave count (3, 5, 10), forced through the walk
+    kernel (path=2) with RecCut-shaped (fused) and plain domain lists, a NaN channel and a constant channel among them."""
+    import torch
+    rng = np.random.default_rng(20261004)
+    ctx = dd.get_context(torch.cuda.current_device())
+    shapes = [(516, 80), (644, 75), (1000, 80), (1028, 65), (1284, 79), (2052, 72), (2556, 80), (2560, 77), (640, 80), (1280, 66)]
+    try:
+        ctx.set_option('path', 2)
+        for ci, (D, m) in enumerate(shapes):
+            lens, doms = [], []
+            for s in range(3):
+                L = int(rng.integers(40, 160))
+                if s < 2:                                       # parts tile the protein + whole protein (fused walk)
+                    cut = int(rng.integers(10, L - 10))
+                    doms.append([f'1-{cut}', f'{cut + 1}-{L}', f'1-{L}'])
+                else:
+                    doms.append([f'1-{L}', f'3-{L - 2}'])
+                lens.append(L)
+            xs = []
+            for s, L in enumerate(lens):
+                x = make_input('esm', L, D, 70_000 + 31 * ci + s)
+                if s == 1:
+                    x[:, D // 2 - 1] = 0.25                     # constant channel next to the fold line -> its layer block is 0
+                if s == 2:
+                    x[5, D - 3] = np.nan
+                xs.append(x)
+            ts = [torch.from_numpy(x).cuda() for x in xs]
+            ctx.set_option('degenerate_channels', 0)
+            out = dd.quantize_batch([dd.LayerBatch(ts, 3, m)], dd.PieceTable(lens, doms)).cpu().numpy()
+            assert ctx.get_option('last_path') == 2
+            row = 0
+            for s in range(3):
+                for dom in doms[s]:
+                    if s == 1:      # constant channel: 0/0 -> NaN -> 0 (the lengths where the reference's FFT leaves round-off
+                        assert not out[row].any()               # noise instead are fenced in tests/test_fences.py)
+                    else:
+                        exp = orc.quantize_matrix([xs[s]], [dom], [3, m])[orc.split_domain(dom, lens[s])[1]]
+                        np.testing.assert_array_equal(out[row].astype(np.int64), exp, err_msg=f'D={D} m={m} seq {s} dom {dom}')
+                    row += 1
+            assert row == out.shape[0]
+            # the constant channel of protein 1 is seen once per job that streams it (3 jobs), whatever lanes hold it
+            assert ctx.get_option('degenerate_channels') == 3, (D, m)
+    finally:
+        ctx.set_option('path', 0)
