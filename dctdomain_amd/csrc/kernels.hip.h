@@ -265,6 +265,20 @@ __device__ inline double unpack_y(unsigned st, double t) {
     return __longlong_as_double((long long)v);
 }
 
+// The same from a state word already shifted to the row's bit pair, the channel's byte at a static position: masks instead
+// of compares and selects (7 instructions; the flush of the walk kernel unpacks 2 x 4 x 128 values per job and wave).
+//   st = 0 -> 0, 1 -> 1.0, 2 -> t, 3 -> NaN (t's bits with exponent and quiet bit forced)
+__device__ inline double unpack_bits(uint32_t word, int pos, double t) {
+    const int m1 = __builtin_amdgcn_sbfe((int)word, (unsigned)pos, 1u);      // -1 where bit 0 of the state is set
+    const int m2 = __builtin_amdgcn_sbfe((int)word, (unsigned)pos + 1u, 1u);  // -1 where bit 1 is set
+    const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+    const uint32_t k = (uint32_t)m1 & 0x3FF00000u;
+    const uint32_t k2 = ((uint32_t)(m1 & m2) & 0x7FF80000u) | k;
+    const uint32_t hi = ((uint32_t)(tb >> 32) & (uint32_t)m2) | k2;
+    const uint32_t lo = (uint32_t)tb & (uint32_t)m2;
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // ---------------------------------------------------------------------------
 // K1: stage A -- HBM-streaming L-axis contraction + per-channel min-max scale.
 //   grid  : n_walks * n_slabs workgroups; workgroup = (walk, slab of 64*VEC channels).
@@ -965,7 +979,7 @@ __global__ __launch_bounds__(S * 64, DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(c
                 constexpr int P = decltype(p_const)::value;
                 static_assert(NT == 5, "slots 0..39 = E, 40..79 = O: the middle column group is half and half");
                 const int g4 = lane >> 4, row = lane & 3;
-                const bool odd_half = (lane & 8) != 0;  // blocks 2, 3 of the middle column group belong to O
+                const double fold_sign = (lane & 8) ? -1.0 : 1.0;  // blocks 2, 3 of the middle column group belong to O
                 double acc[P][NT];
 #pragma unroll
                 for (int g = 0; g < P; ++g)
@@ -990,21 +1004,25 @@ __global__ __launch_bounds__(S * 64, DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(c
                 for (int qi = 0; qi < n_q; ++qi) {
                     const int pl0 = 16 * qi + 4 * g4;  // my pairs of this group: pl0 + r
                     const int p0 = wave * (kWalkChannels / 2) + pl0;
+                    // pairs past D/2 (D % 32 != 0) get state 0 = value 0, whatever the slots hold: byte r of the word of the
+                    // channels d, byte 3 - r of the mirrors' word
+                    const int nl = min(4, max(0, half - p0));
+                    const uint32_t lm = nl >= 4 ? 0xffffffffu : ((1u << (8 * nl)) - 1u);
+                    const uint32_t lmm = nl >= 4 ? 0xffffffffu : (nl <= 0 ? 0u : ~((1u << (8 * (4 - nl))) - 1u));
                     uint32_t c4[P], c4m[P];
 #pragma unroll
                     for (int g = 0; g < P; ++g) {
-                        c4[g] = lds_c[wave][g][pl0 >> 2];
-                        c4m[g] = lds_c[wave][g][32 + (pl0 >> 2)];
+                        c4[g] = (lds_c[wave][g][pl0 >> 2] & lm) >> (2 * row);
+                        c4m[g] = (lds_c[wave][g][32 + (pl0 >> 2)] & lmm) >> (2 * row);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const bool live = p0 + r < half;  // pairs past D/2 (D % 32 != 0): zero, whatever the slots hold
 #pragma unroll
                         for (int g = 0; g < P; ++g) {
-                            const double y = unpack_y((c4[g] >> (8 * r + 2 * row)) & 3u, lds_t[wave][g][pl0 + r]);
-                            const double ym = unpack_y((c4m[g] >> (8 * (3 - r) + 2 * row)) & 3u, lds_t[wave][g][128 + pl0 + 3 - r]);
-                            const double au = live ? y + ym : 0.0, av = live ? y - ym : 0.0;
-                            const double ax = odd_half ? av : au;
+                            const double y = unpack_bits(c4[g], 8 * r, lds_t[wave][g][pl0 + r]);
+                            const double ym = unpack_bits(c4m[g], 8 * (3 - r), lds_t[wave][g][128 + pl0 + 3 - r]);
+                            const double au = y + ym, av = y - ym;
+                            const double ax = fma(fold_sign, ym, y);  // blocks 0, 1 of the middle column group: u, blocks 2, 3: v
                             // NT * P independent accumulators between two uses of one
 #pragma unroll
                             for (int c = 0; c < NT; ++c)
