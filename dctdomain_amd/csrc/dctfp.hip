@@ -545,15 +545,16 @@ int launch_walk_u(const WParams& p, int unroll, bool fused) {
     return DCTFP_OK;
 }
 
-// Instantiated shapes: S waves cover up to 256 S channels; G = jobs per flush is bounded by the LDS (2304 B per wave and
-// job: G = 4 leaves room for 17 waves per CU, G = 3 for 23).
+// Instantiated shapes: S waves cover up to 256 S channels; G = jobs per flush <= 4 (the rows of an MFMA tile), bounded by
+// the LDS too (2304 B per wave and job: G = 4 leaves room for 17 waves per CU, G = 3 for 23).  A flush costs the same
+// MFMAs for 1..4 jobs, so G = 4 is the default everywhere.
 int launch_walk(const WParams& p, int s, int g, int unroll, bool fused) {
     if (s == 3 && g == 4) return launch_walk_u<3, 4>(p, unroll, fused);
     if (s == 3 && g == 3) return launch_walk_u<3, 3>(p, unroll, fused);
     if (s == 5 && g == 4) return launch_walk_u<5, 4>(p, unroll, fused);
     if (s == 5 && g == 3) return launch_walk_u<5, 3>(p, unroll, fused);
+    if (s == 10 && g == 4) return launch_walk_u<10, 4>(p, unroll, fused);
     if (s == 10 && g == 3) return launch_walk_u<10, 3>(p, unroll, fused);
-    if (s == 10 && g == 2) return launch_walk_u<10, 2>(p, unroll, fused);
     return fail(DCTFP_ERR_INVALID, "walk kernel: no build for %d waves x %d jobs per flush", s, g);
 }
 
@@ -674,7 +675,7 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "path must be 0 (auto), 1 (stage A -> Y' -> stage B) or 2 (walk kernel wherever its shapes allow)");
         ctx->opt_path = value;
     } else if (n == "ab_group") {
-        if (value != 0 && (value < 2 || value > 4)) return fail(DCTFP_ERR_INVALID, "ab_group must be 0 (auto) or 2..4 jobs per flush");
+        if (value != 0 && value != 3 && value != 4) return fail(DCTFP_ERR_INVALID, "ab_group must be 0 (auto), 3 or 4 jobs per flush");
         ctx->opt_ab_group = value;
     } else if (n == "ab_unroll") {
         if (value != 0 && value != 4 && value != 6 && value != 8) return fail(DCTFP_ERR_INVALID, "ab_unroll must be 0 (auto), 4, 6 or 8");
@@ -984,7 +985,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         if (use_walk) {
             walk_s = g.n_cols <= 768 ? 3 : (g.n_cols <= 1280 ? 5 : 10);
             // jobs per flush: 4 leaves LDS for 17 waves per CU (S = 10: 3, so that two workgroups fit)
-            walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : (walk_s == 10 ? 3 : 4);
+            walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : 4;
             for (int64_t j = 0; j < n_jobs;) {
                 const int64_t d = j % n_domains;
                 Walk& wk = hwalk[n_walks++];

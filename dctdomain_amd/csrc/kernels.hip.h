@@ -963,7 +963,7 @@ __global__ __launch_bounds__(S * 64, DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(c
             const bool last = (wi + 1 == run.n_walks) && (part + 1 == n_walk_jobs);
             if (pending < (uint32_t)G && !last) continue;
 
-            // ---- flush: stage B of the `pending` jobs in LDS (P = pending as a compile-time count)
+            // ---- flush: stage B of the `pending` jobs in LDS
             // Both cosine factors of St[d][c] = sum_k cos_m(k, c) cos_D(k, d) are mirror (anti)symmetric:
             //   St[d][c] = E[d][c] + O[d][c],  St[D-1-d][c] = St[d][m-1-c] = E[d][c] - O[d][c]     (E: even k, O: odd k)
             // so with u = y[d] + y[D-1-d], v = y[d] - y[D-1-d] over the D/2 channel pairs and the m/2 left columns
@@ -975,16 +975,20 @@ __global__ __launch_bounds__(S * 64, DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(c
             // ascending channel order (pair p of the wave <-> entries p and 128 + (p ^ 3)).
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            auto contract = [&](auto p_const) {
-                constexpr int P = decltype(p_const)::value;
+            // The 4 rows of an MFMA tile are the 4 jobs of the flush: lane (i = lane & 3, k = lane >> 4) unpacks job i's value
+            // of pair k for row j, three tiles (j = 0, 1, 2) per column group -- 15 MFMAs per k-step whatever `pending` is
+            // (rows of jobs that are not there are computed on stale slots and never stored).
+            {
                 static_assert(NT == 5, "slots 0..39 = E, 40..79 = O: the middle column group is half and half");
-                const int g4 = lane >> 4, row = lane & 3;
+                static_assert(G >= 1 && G <= 4, "one MFMA row per job of the flush");
+                const int g4 = lane >> 4;
+                const int gs = min(lane & 3, G - 1);                 // my job's slot
                 const double fold_sign = (lane & 8) ? -1.0 : 1.0;  // blocks 2, 3 of the middle column group belong to O
-                double acc[P][NT];
+                double acc[3][NT];
 #pragma unroll
-                for (int g = 0; g < P; ++g)
+                for (int jr = 0; jr < 3; ++jr)
 #pragma unroll
-                    for (int c = 0; c < NT; ++c) acc[g][c] = 0.0;
+                    for (int c = 0; c < NT; ++c) acc[jr][c] = 0.0;
                 // B fragments of k-step (q, r): NT column groups x 8 bytes per lane
                 const double* __restrict__ sq = stf + (size_t)wave * (kWalkChannels / 32) * 4 * NT * 64 + lane;
                 auto fetch_b = [&](double (&b)[NT], int step) {
@@ -1009,43 +1013,33 @@ __global__ __launch_bounds__(S * 64, DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(c
                     const int nl = min(4, max(0, half - p0));
                     const uint32_t lm = nl >= 4 ? 0xffffffffu : ((1u << (8 * nl)) - 1u);
                     const uint32_t lmm = nl >= 4 ? 0xffffffffu : (nl <= 0 ? 0u : ~((1u << (8 * (4 - nl))) - 1u));
-                    uint32_t c4[P], c4m[P];
-#pragma unroll
-                    for (int g = 0; g < P; ++g) {
-                        c4[g] = (lds_c[wave][g][pl0 >> 2] & lm) >> (2 * row);
-                        c4m[g] = (lds_c[wave][g][32 + (pl0 >> 2)] & lmm) >> (2 * row);
-                    }
+                    const uint32_t cw = lds_c[wave][gs][pl0 >> 2] & lm;
+                    const uint32_t cwm = lds_c[wave][gs][32 + (pl0 >> 2)] & lmm;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        const double t = lds_t[wave][gs][pl0 + r], tm = lds_t[wave][gs][128 + pl0 + 3 - r];
 #pragma unroll
-                        for (int g = 0; g < P; ++g) {
-                            const double y = unpack_bits(c4[g], 8 * r, lds_t[wave][g][pl0 + r]);
-                            const double ym = unpack_bits(c4m[g], 8 * (3 - r), lds_t[wave][g][128 + pl0 + 3 - r]);
+                        for (int jr = 0; jr < 3; ++jr) {
+                            const double y = unpack_bits(cw, 8 * r + 2 * jr, t);
+                            const double ym = unpack_bits(cwm, 8 * (3 - r) + 2 * jr, tm);
                             const double au = y + ym, av = y - ym;
                             const double ax = fma(fold_sign, ym, y);  // blocks 0, 1 of the middle column group: u, blocks 2, 3: v
-                            // NT * P independent accumulators between two uses of one
+                            // 3 * NT independent accumulators between two uses of one
 #pragma unroll
                             for (int c = 0; c < NT; ++c)
-                                acc[g][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(c < 2 ? au : (c == 2 ? ax : av), bq[r % DEPTH][c], acc[g][c], 0, 0, 0);
+                                acc[jr][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(c < 2 ? au : (c == 2 ? ax : av), bq[r % DEPTH][c], acc[jr][c], 0, 0, 0);
                         }
                         fetch_b(bq[r % DEPTH], min(4 * qi + r + DEPTH, last_step));
                     }
                 }
-                // partial blocks -> my slots (the Y' in them is consumed): zp[row][slot], rows 0..2 = lanes 0..47
+                // partial blocks -> my slots (the Y' in them is consumed): tile row = lane >> 4 = job, zp[row jr][slot]
                 __builtin_amdgcn_wave_barrier();
-                if (lane < 48) {
+                if ((uint32_t)(lane >> 4) < pending) {
 #pragma unroll
-                    for (int g = 0; g < P; ++g)
+                    for (int jr = 0; jr < 3; ++jr)
 #pragma unroll
-                        for (int c = 0; c < NT; ++c) lds_t[wave][g][(lane >> 4) * (NT * 16) + c * 16 + (lane & 15)] = acc[g][c];
+                        for (int c = 0; c < NT; ++c) lds_t[wave][lane >> 4][jr * (NT * 16) + c * 16 + (lane & 15)] = acc[jr][c];
                 }
-            };
-            static_assert(G >= 1 && G <= 4, "flush dispatch covers 1..4 jobs");
-            switch (pending) {
-                case 1: contract(std::integral_constant<int, 1>{}); break;
-                case 2: if constexpr (G >= 2) contract(std::integral_constant<int, 2>{}); break;
-                case 3: if constexpr (G >= 3) contract(std::integral_constant<int, 3>{}); break;
-                default: if constexpr (G >= 4) contract(std::integral_constant<int, 4>{}); break;
             }
             __syncthreads();
             // sum over the waves in wave order, Z[c] = ZE[c] + ZO[c] and Z[m-1-c] = ZE[c] - ZO[c], per-row min-max scale, int8

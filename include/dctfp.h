@@ -186,7 +186,7 @@ int dctfp_host_device_pointer(void* host, void** dev);
  *                  for n = 3, 64 < m <= 80, float32 rows, 512 <= D <= 1280; stage A -> scratch -> stage B otherwise;
  *                  1 = always the two-kernel path; 2 = the walk kernel wherever its shapes allow (also D <= 2560)
  *   "last_path"    read only: which kernels the last dctfp_quantize launched (1 = two kernels, 2 = walk kernel)
- *   "ab_group"     walk kernel: jobs per stage-B flush (0 = by shape, 2..4)
+ *   "ab_group"     walk kernel: jobs per stage-B flush (0 = auto = 4, 3, 4)
  *   "ab_unroll"    walk kernel: rows in flight per wave (0 = 8; 4, 6, 8)
  *   "ab_run_jobs"  walk kernel: jobs per workgroup (0 = by batch size)
  *   "stage_b"      two-kernel path: 0 = plain VALU stage B, 1 = MFMA f64 kernel (default)
