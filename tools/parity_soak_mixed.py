@@ -1,6 +1,6 @@
 """Parity soak of the multi-domain path: N random proteins with RecCut-shaped domain lists (parts that tile the protein,
-discontinuous parts, + the whole protein) and pfam-like lengths through the GPU path (fused walks: the walk kernel at
-D = 640 / 1280, the two-kernel path at D = 2560) and through the faithful CPU oracle (scipy.fft, like the reference) on
+discontinuous parts, + the whole protein) and pfam-like lengths through the GPU path (fused walks of the walk kernel at
+D = 640 / 1280 / 2560) and through the faithful CPU oracle (scipy.fft, like the reference) on
 the host cores; counts mismatching int8 values.  Checker use of oracle/ only (a test tool, not product code).
 usage: python tools/parity_soak_mixed.py [n_proteins] [procs] [D]"""
 import os, sys, time
