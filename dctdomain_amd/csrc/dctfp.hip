@@ -1235,6 +1235,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             EventPair* ep = nullptr;
             rc = prof_begin(ctx, 0, stream, &ep);
             if (rc) return rc;
+            // small call: stage B over 64-channel slabs (stage_b_slab_kernel), their partial blocks in the split scratch
+            const int n_kslabs = (g.n_cols + kSlabChannels - 1) / kSlabChannels;
+            auto zpart_bytes = [&](int64_t jobs_here) { return (size_t)jobs_here * n_kslabs * n * m * sizeof(double); };
+            double* zpart = nullptr;
             {
                 AParams ap;
                 ap.jobs = dja + j0;
@@ -1259,15 +1263,23 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                     uint32_t chunk_rows = (uint32_t)((max_len_all + want_chunks - 1) / want_chunks);
                     chunk_rows = std::max<uint32_t>(32, (chunk_rows + 31) / 32 * 32);  // 8 waves x 4 rows in flight
                     const int n_chunks = (int)((max_len_all + chunk_rows - 1) / chunk_rows);
-                    rc = ctx->split_ws.ensure((size_t)jn * n_chunks * nk * ldy * sizeof(double));
+                    const size_t partial_bytes = (size_t)jn * n_chunks * nk * ldy * sizeof(double);
+                    rc = ctx->split_ws.ensure(partial_bytes + (small_b ? zpart_bytes(jn) : 0));
                     if (rc) return rc;
                     static const InvTab<3> inv3 = make_inv<3>();
                     hipLaunchKernelGGL((stage_a_split_kernel<float, 3, 4, 8, 4>), dim3((unsigned)(jn * n_chunks * n_slabs)), dim3(512), 0, stream,
                                        dja + j0, dpc, (double*)ctx->split_ws.p, n_chunks, chunk_rows, g.n_cols, g.ld, ldy, n_slabs);
                     HIP_TRY(hipGetLastError());
-                    hipLaunchKernelGGL((stage_a_combine_kernel<3>), dim3((unsigned)((ldy + 255) / 256), (unsigned)jn), dim3(256), 0, stream,
-                                       (const double*)ctx->split_ws.p, n_chunks, yprime, (int64_t)job_bytes, packed ? 1 : 0, g.n_cols, ldy,
-                                       inv3, ctx->degenerate);
+                    if (small_b) {  // the slabs of stage B add the chunks and scale their channels themselves
+                        zpart = (double*)((char*)ctx->split_ws.p + partial_bytes);
+                        hipLaunchKernelGGL((stage_b_slab_kernel<true>), dim3((unsigned)n_kslabs, (unsigned)jn), dim3(256), 0, stream,
+                                           (const double*)nullptr, ldy, (const double*)ctx->split_ws.p, n_chunks, inv3, ctx->degenerate,
+                                           g.n_cols, (const double*)st->dev, st->cp, n, m, zpart);
+                    } else {
+                        hipLaunchKernelGGL((stage_a_combine_kernel<3>), dim3((unsigned)((ldy + 255) / 256), (unsigned)jn), dim3(256), 0, stream,
+                                           (const double*)ctx->split_ws.p, n_chunks, yprime, (int64_t)job_bytes, packed ? 1 : 0, g.n_cols, ldy,
+                                           inv3, ctx->degenerate);
+                    }
                     HIP_TRY(hipGetLastError());
                 }
                 int waves = (int)ctx->opt_a_waves;
@@ -1298,6 +1310,18 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 const int64_t rows = jn * n;
                 launch_b_mfma(st->cp / 16, packed, (unsigned)((rows + kBWaves * 16 - 1) / (kBWaves * 16)), sb, yprime, (int64_t)job_bytes, rows, ldy,
                               st->dev, djb + j0, n, m, out);
+            } else if (small_b) {
+                if (!zpart) {  // stage A wrote Y' (no row split): the slabs read it
+                    rc = ctx->split_ws.ensure(zpart_bytes(jn));
+                    if (rc) return rc;
+                    zpart = (double*)ctx->split_ws.p;
+                    static const InvTab<3> inv3 = make_inv<3>();
+                    hipLaunchKernelGGL((stage_b_slab_kernel<false>), dim3((unsigned)n_kslabs, (unsigned)jn), dim3(256), 0, sb,
+                                       (const double*)yprime, ldy, (const double*)nullptr, 0, inv3, ctx->degenerate, g.n_cols,
+                                       (const double*)st->dev, st->cp, n, m, zpart);
+                    HIP_TRY(hipGetLastError());
+                }
+                hipLaunchKernelGGL(stage_b_finish_kernel, dim3((unsigned)jn), dim3(256), 0, sb, (const double*)zpart, n_kslabs, djb + j0, n, m, out);
             } else {
                 hipLaunchKernelGGL(stage_b_valu_kernel, dim3((unsigned)jn), dim3(1024), 0, sb, (const double*)yprime, ldy, g.n_cols,
                                    st->dev, st->cp, djb + j0, n, m, out);

@@ -767,6 +767,97 @@ __global__ __launch_bounds__(1024) void stage_b_valu_kernel(const double* __rest
 }
 
 // ---------------------------------------------------------------------------
+// K2s: stage B of a small call (a protein per call: one or two jobs).  One workgroup per job spent 46 us on the D-long
+// sums -- three quarters of the call's GPU time -- so the channels are spread over workgroups of 64: each adds its slab's
+// share of the job's n x m block (FROM_SPLIT: after adding the row chunks of stage_a_split_kernel and scaling its 64
+// channels itself, which saves the combine launch), stage_b_finish_kernel adds the slabs in slab order (deterministic),
+// scales the rows and writes the int8.
+// ---------------------------------------------------------------------------
+constexpr int kSlabChannels = 64;
+
+template <bool FROM_SPLIT>
+__global__ __launch_bounds__(256) void stage_b_slab_kernel(const double* __restrict__ yp, int ldy, const double* __restrict__ partial,
+                                                            int n_chunks, InvTab<3> inv, unsigned long long* __restrict__ degenerate,
+                                                            int n_cols, const double* __restrict__ st, int cp, int n, int m,
+                                                            double* __restrict__ zpart) {
+    __shared__ double ys[DCTFP_MAX_N_K][kSlabChannels];
+    const int job = blockIdx.y, ks = blockIdx.x;
+    const int d0 = ks * kSlabChannels;
+    const int dn = min(kSlabChannels, n_cols - d0);
+    if constexpr (FROM_SPLIT) {  // n = 3: my channel's chunk sums -> scaled values
+        if (threadIdx.x < kSlabChannels) {
+            const int d = d0 + (int)threadIdx.x;
+            double f[2] = {0.0, 0.0};
+            if (d < ldy)
+                for (int c = 0; c < n_chunks; ++c)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) f[k] += partial[(((size_t)job * n_chunks + c) * 2 + k) * ldy + d];
+            double z[3];
+            scale_channel<3>(f, inv, d >= n_cols, z, degenerate);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ys[j][threadIdx.x] = z[j];
+        }
+    } else {
+        const double* __restrict__ yj = yp + (size_t)job * n * ldy;
+        for (int i = threadIdx.x; i < n * kSlabChannels; i += 256) {
+            const int j = i / kSlabChannels, t = i % kSlabChannels;
+            ys[j][t] = (t < dn) ? yj[(size_t)j * ldy + d0 + t] : 0.0;
+        }
+    }
+    __syncthreads();
+    const int n_out = n * m;
+    double* __restrict__ zp = zpart + ((size_t)job * gridDim.x + ks) * n_out;
+    for (int o = threadIdx.x; o < n_out; o += 256) {
+        const int j = o / m, c = o % m;
+        const double* __restrict__ sc = st + (size_t)d0 * cp + c;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int t = 0;
+        for (; t + 3 < dn; t += 4) {
+            a0 = fma(ys[j][t], sc[(size_t)t * cp], a0);
+            a1 = fma(ys[j][t + 1], sc[(size_t)(t + 1) * cp], a1);
+            a2 = fma(ys[j][t + 2], sc[(size_t)(t + 2) * cp], a2);
+            a3 = fma(ys[j][t + 3], sc[(size_t)(t + 3) * cp], a3);
+        }
+        for (; t < dn; ++t) a0 = fma(ys[j][t], sc[(size_t)t * cp], a0);
+        zp[o] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+__global__ __launch_bounds__(256) void stage_b_finish_kernel(const double* __restrict__ zpart, int n_kslabs, const JobB* __restrict__ jobs,
+                                                              int n, int m, int8_t* __restrict__ out) {
+    __shared__ double bl[DCTFP_MAX_N_K * DCTFP_MAX_M_K];
+    const int job = blockIdx.x;
+    const int n_out = n * m;
+    const double* __restrict__ zj = zpart + (size_t)job * n_kslabs * n_out;
+    for (int o = threadIdx.x; o < n_out; o += 256) {
+        double sum = 0.0;
+        for (int ks = 0; ks < n_kslabs; ++ks) sum += zj[(size_t)ks * n_out + o];
+        bl[o] = sum;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < n; j += 4) {
+        double mn = INFINITY, mx = -INFINITY;
+        int bad = 0;
+        for (int c = lane; c < m; c += 64) {
+            const double v = bl[j * m + c];
+            bad |= (v != v) ? 1 : 0;
+            mn = fmin(mn, v);
+            mx = fmax(mx, v);
+        }
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            mn = fmin(mn, __shfl_xor(mn, s));
+            mx = fmax(mx, __shfl_xor(mx, s));
+            bad |= __shfl_xor(bad, s);
+        }
+        int8_t* __restrict__ o = out + jobs[job].out_off + (int64_t)j * m;
+        const double den = mx - mn;
+        for (int c = lane; c < m; c += 64) o[c] = quant127(bl[j * m + c] - mn, den, bad != 0);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K3: stage A and stage B in ONE kernel ("walk" kernel; n = 3, m <= 80, float32 rows read as 16 B per lane).
 //
 // The two-kernel path sends Y' (9 B per channel and job) through HBM.  That is 0.45 % of the bytes at the headline
