@@ -50,7 +50,8 @@ _lib_lock = threading.Lock()
 
 EXPORTS = ('dctfp_version', 'dctfp_last_error', 'dctfp_create', 'dctfp_destroy', 'dctfp_quantize',
            'dctfp_idct_quant', 'dctfp_scale', 'dctfp_gather_rows', 'dctfp_contact_topk',
-           'dctfp_contact_count', 'dctfp_stitch', 'dctfp_l1_matrix', 'dctfp_block_min', 'dctfp_row_select', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile', 'dctfp_host_device_pointer')
+           'dctfp_contact_count', 'dctfp_stitch', 'dctfp_l1_matrix', 'dctfp_block_min', 'dctfp_row_select', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile', 'dctfp_host_device_pointer',
+           'dctfp_stream_synchronize')
 
 
 def load(path: str = None):
@@ -103,6 +104,7 @@ def _configure(lib):
         lib.dctfp_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
         lib.dctfp_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         lib.dctfp_host_device_pointer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.dctfp_stream_synchronize.argtypes = [C.c_void_p]
         for fn in EXPORTS:
             if fn not in ('dctfp_last_error', 'dctfp_contact_count'):
                 getattr(lib, fn).restype = C.c_int

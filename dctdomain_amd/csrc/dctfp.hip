@@ -1677,6 +1677,11 @@ int dctfp_host_device_pointer(void* host, void** dev) {
     return DCTFP_OK;
 }
 
+int dctfp_stream_synchronize(void* stream) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return DCTFP_OK;
+}
+
 int64_t dctfp_contact_count(int32_t n_res, double t) {
     if (n_res < 6) return 0;
     const int64_t cand = (int64_t)(n_res - 5) * (n_res - 4) / 2;  // pairs with j >= i + 5

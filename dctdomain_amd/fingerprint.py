@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .batch import LayerBatch, PieceTable, quantize_batch
+from .batch import PieceTable, host_pointer
 from .domains import split_domain
 
 
@@ -171,7 +171,7 @@ class Fingerprint:
 
         One protein per call is the reference's calling pattern, not the fast one: a call costs a
         table upload, one or two kernel launches and a device -> host copy of 480 bytes per domain
-        (about 60 us in all).  ``make_db.fingerprint_batch`` / ``batch.quantize_batch`` take many
+        (about 70 us in all).  ``make_db.fingerprint_batch`` / ``batch.quantize_batch`` take many
         proteins per call and are the throughput path."""
         embeds = list(self.embed.values())
         if len(qdim) < 2 * len(embeds):
@@ -184,8 +184,12 @@ class Fingerprint:
         mats = [_to_device_matrix(e, device, keep_half=True) for e in embeds]
 
         # layers are grouped while they share the row count (one piece table per group); every group is
-        # enqueued first, the results come back in ONE pinned copy and one synchronisation
-        groups = []           # (table, device int8 tensor, first layer, last layer)
+        # enqueued first, the results land in ONE pinned buffer and are read after one synchronisation.
+        # One protein per call is bound by host time: the C ABI is called directly (no LayerBatch / quantize_batch
+        # objects), on torch's current raw stream, and waited for with dctfp_stream_synchronize.
+        groups = []           # (table, offset into the pinned buffer, width, first layer, last layer)
+        dev = mats[0].device if mats else None
+        stream = _raw_stream(dev) if mats else 0
         i = 0
         while i < len(mats):
             j = i
@@ -194,20 +198,19 @@ class Fingerprint:
                 j += 1
             table = PieceTable([mats[i].shape[0]], [self.domains])
             if table.n_domains:
-                layers = [LayerBatch([mats[k]], qdim[2 * k], qdim[2 * k + 1]) for k in range(i, j + 1)]
-                width = sum(l.n_keep * l.m_keep for l in layers)
-                out = _result_buffer(mats[i].device, table.n_domains, width)
-                quantize_batch(layers, table, out=out)
-                groups.append((table, out, i, j))
+                width = sum(qdim[2 * k] * qdim[2 * k + 1] for k in range(i, j + 1))
+                off, out_ptr = _result_slot(table.n_domains * width)
+                _enqueue_group(mats[i:j + 1], qdim[2 * i:2 * j + 2], table, out_ptr, width, stream)
+                groups.append((table, off, width, i, j))
             i = j + 1
-        hosts = _fetch_results([g[1] for g in groups], mats[0].device if mats else None)
+        hosts = _fetch_results(groups, stream)
 
         # quants[key] = the blocks of every layer, layer-major, then domain order (:184-196); a key that occurs
         # twice (two domain strings cleaned to the same key) is extended twice, as there
         pieces = {}
         for key, value in self.quants.items():
             pieces[key] = [np.asarray(value)]
-        for (table, _, first, last), host in zip(groups, hosts):
+        for (table, _, _, first, last), host in zip(groups, hosts):
             off = 0
             for k in range(first, last + 1):
                 nm = qdim[2 * k] * qdim[2 * k + 1]
@@ -222,31 +225,72 @@ class Fingerprint:
 
 # scratch of the one-protein-per-call path: a pinned host buffer the kernels write their int8 results into directly
 # (480 bytes per domain over PCIe: no device buffer, no copy engine in the chain -- its latency was most of a call)
-_RESULTS = {'pin': None, 'used': 0}
+_RESULTS = {'pin': None, 'np': None, 'dev': 0, 'used': 0}
 
 
-def _result_buffer(device, n_rows: int, width: int) -> torch.Tensor:
-    """A (n_rows, width) int8 view of the pinned result buffer.  Several views may be handed out between two
-    ``_fetch_results`` calls (layer groups of one protein): they are carved one after another."""
+def _raw_stream(device) -> int:
+    """torch's current stream on ``device`` as a hipStream_t value."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    try:
+        return int(torch._C._cuda_getCurrentRawStream(idx))
+    except AttributeError:                                   # (older / newer torch without the private accessor)
+        return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _result_slot(nbytes: int):
+    """``nbytes`` of the pinned result buffer: (offset, address under which the GPU sees them).  Several slots may be
+    handed out between two ``_fetch_results`` calls (layer groups of one protein): they are carved one after another."""
     st = _RESULTS
-    need = n_rows * width
-    if st['pin'] is None or st['used'] + need > st['pin'].numel():
-        # (views handed out earlier keep their storage alive; only new views come from the new buffer)
-        st['pin'] = torch.empty(max(1 << 16, 2 * need), dtype=torch.int8, pin_memory=True)
+    if st['pin'] is None or st['used'] + nbytes > st['pin'].numel():
+        # (a buffer that is being replaced holds no pending results: its slots were fetched or never enqueued on)
+        if st['pin'] is not None and st['used']:
+            _lib.check(_lib.load().dctfp_stream_synchronize(None))
+        st['pin'] = torch.empty(max(1 << 16, 2 * nbytes), dtype=torch.int8, pin_memory=True)
+        st['np'] = st['pin'].numpy()
+        st['dev'] = host_pointer(st['pin'])
         st['used'] = 0
-    view = st['pin'][st['used']:st['used'] + need].view(n_rows, width)
-    st['used'] += need
-    return view
+    off = st['used']
+    st['used'] += nbytes
+    return off, st['dev'] + off
 
 
-def _fetch_results(views, device=None):
-    """Views handed out by ``_result_buffer`` -> numpy arrays (copies) after ONE stream synchronisation."""
-    if not views:
+def _enqueue_group(mats, qd, table, out_ptr: int, width: int, stream: int):
+    """``dctfp_quantize`` (include/dctfp.h) for the layers of one protein that share the row count."""
+    k = len(mats)
+    arr = (_lib.Layer * k)()
+    ptrs = (C.c_void_p * k)()
+    off = 0
+    for i, t in enumerate(mats):
+        ptrs[i] = t.data_ptr()
+        a = arr[i]
+        a.seq_data = C.cast(C.byref(ptrs, i * C.sizeof(C.c_void_p)), C.POINTER(C.c_void_p))
+        a.ld = t.stride(0) if t.shape[0] > 1 else t.shape[1]
+        a.n_cols = t.shape[1]
+        a.dtype = _DTYPE_CODE[t.dtype]
+        a.n_keep = int(qd[2 * i])
+        a.m_keep = int(qd[2 * i + 1])
+        a.out_offset = off
+        off += a.n_keep * a.m_keep
+    d = mats[0].device
+    ctx = _lib.get_context(d.index if d.index is not None else torch.cuda.current_device())
+    lib = ctx._lib
+    _lib.check(lib.dctfp_quantize(ctx.handle, arr, k, 1, table.seq_rows.ctypes.data, table.pieces.ctypes.data,
+                                  len(table.pieces), table.n_domains, out_ptr, width, stream))
+
+
+def _fetch_results(groups, stream: int):
+    """Slots handed out by ``_result_slot`` -> numpy arrays (copies) after ONE stream synchronisation."""
+    if not groups:
         return []
-    torch.cuda.current_stream(device).synchronize()
-    out = [v.numpy().copy() for v in views]
+    _lib.check(_lib.load().dctfp_stream_synchronize(stream))
+    buf = _RESULTS['np']
+    out = [buf[off:off + table.n_domains * width].reshape(table.n_domains, width).copy() for table, off, width, _, _ in groups]
     _RESULTS['used'] = 0
     return out
+
+
+_DTYPE_CODE = {torch.float32: _lib.DCTFP_F32, torch.float64: _lib.DCTFP_F64, torch.float16: _lib.DCTFP_F16,
+               torch.bfloat16: _lib.DCTFP_BF16}
 
 
 def _dtype_code(t: torch.Tensor) -> int:

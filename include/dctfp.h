@@ -181,9 +181,14 @@ int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_
  * into host memory: no device buffer, no copy -- what a one-protein-per-call user wants (480 bytes per domain). */
 int dctfp_host_device_pointer(void* host, void** dev);
 
+/* Blocks until everything enqueued on `stream` (a hipStream_t, NULL = the default stream) is done -- for bindings that
+ * have no HIP binding of their own: the synchronous one-protein-per-call user waits here for the bytes that
+ * dctfp_quantize writes into its pinned result buffer. */
+int dctfp_stream_synchronize(void* stream);
+
 /* Tuning / instrumentation knobs (no reference counterpart).
  *   "path"         0 (default) = by shape: the walk kernel (stage A + stage B in one launch, nothing but int8 written)
- *                  for n = 3, 64 < m <= 80, float32 rows, 512 <= D <= 1280; stage A -> scratch -> stage B otherwise;
+ *                  for n = 3, 64 < m <= 80, float32 rows, 512 <= D <= 2560; stage A -> scratch -> stage B otherwise;
  *                  1 = always the two-kernel path; 2 = the walk kernel wherever its shapes allow (also D <= 2560)
  *   "last_path"    read only: which kernels the last dctfp_quantize launched (1 = two kernels, 2 = walk kernel)
  *   "ab_group"     walk kernel: jobs per stage-B flush (0 = auto = 4, 3, 4)
