@@ -580,7 +580,8 @@ def test_walk_kernel_widths_and_kept_columns_against_oracle(dd):
     import torch
     rng = np.random.default_rng(20261004)
     ctx = dd.get_context(torch.cuda.current_device())
-    shapes = [(516, 80), (644, 75), (1000, 80), (1028, 65), (1284, 79), (2052, 72), (2556, 80), (2560, 77), (640, 80), (1280, 66)]
+    shapes = [(512, 80), (516, 80), (644, 75), (768, 80), (772, 80), (1000, 80), (1028, 65), (1284, 79), (1288, 70), (2052, 72),
+              (2556, 80), (2560, 77), (640, 80), (1280, 66)]
     try:
         ctx.set_option('path', 2)
         for ci, (D, m) in enumerate(shapes):
