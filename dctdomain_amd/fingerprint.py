@@ -17,6 +17,7 @@ CPU implementation behind this class: without libdctfp.so and a GPU it raises.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -199,9 +200,9 @@ class Fingerprint:
             table = PieceTable([mats[i].shape[0]], [self.domains])
             if table.n_domains:
                 width = sum(qdim[2 * k] * qdim[2 * k + 1] for k in range(i, j + 1))
-                off, out_ptr = _result_slot(table.n_domains * width)
+                buf, off, out_ptr = _result_slot(table.n_domains * width)
                 _enqueue_group(mats[i:j + 1], qdim[2 * i:2 * j + 2], table, out_ptr, width, stream)
-                groups.append((table, off, width, i, j))
+                groups.append((table, (buf, off), width, i, j))
             i = j + 1
         hosts = _fetch_results(groups, stream)
 
@@ -225,7 +226,15 @@ class Fingerprint:
 
 # scratch of the one-protein-per-call path: a pinned host buffer the kernels write their int8 results into directly
 # (480 bytes per domain over PCIe: no device buffer, no copy engine in the chain -- its latency was most of a call)
-_RESULTS = {'pin': None, 'np': None, 'dev': 0, 'used': 0}
+class _Results(threading.local):
+    """Per thread: the pinned buffer, its numpy view, the address the GPU sees it under, bytes handed out."""
+    pin = None
+    np = None
+    dev = 0
+    used = 0
+
+
+_RESULTS = _Results()
 
 
 def _raw_stream(device) -> int:
@@ -238,20 +247,18 @@ def _raw_stream(device) -> int:
 
 
 def _result_slot(nbytes: int):
-    """``nbytes`` of the pinned result buffer: (offset, address under which the GPU sees them).  Several slots may be
-    handed out between two ``_fetch_results`` calls (layer groups of one protein): they are carved one after another."""
+    """``nbytes`` of the pinned result buffer: (numpy view of the buffer, offset, address under which the GPU sees the
+    slot).  Several slots may be handed out between two ``_fetch_results`` calls (layer groups of one protein): they are
+    carved one after another; a slot keeps its buffer alive through the numpy view if a larger one replaces it."""
     st = _RESULTS
-    if st['pin'] is None or st['used'] + nbytes > st['pin'].numel():
-        # (a buffer that is being replaced holds no pending results: its slots were fetched or never enqueued on)
-        if st['pin'] is not None and st['used']:
-            _lib.check(_lib.load().dctfp_stream_synchronize(None))
-        st['pin'] = torch.empty(max(1 << 16, 2 * nbytes), dtype=torch.int8, pin_memory=True)
-        st['np'] = st['pin'].numpy()
-        st['dev'] = host_pointer(st['pin'])
-        st['used'] = 0
-    off = st['used']
-    st['used'] += nbytes
-    return off, st['dev'] + off
+    if st.pin is None or st.used + nbytes > st.pin.numel():
+        st.pin = torch.empty(max(1 << 16, 2 * nbytes), dtype=torch.int8, pin_memory=True)
+        st.np = st.pin.numpy()
+        st.dev = host_pointer(st.pin)
+        st.used = 0
+    off = st.used
+    st.used += nbytes
+    return st.np, off, st.dev + off
 
 
 def _enqueue_group(mats, qd, table, out_ptr: int, width: int, stream: int):
@@ -283,9 +290,8 @@ def _fetch_results(groups, stream: int):
     if not groups:
         return []
     _lib.check(_lib.load().dctfp_stream_synchronize(stream))
-    buf = _RESULTS['np']
-    out = [buf[off:off + table.n_domains * width].reshape(table.n_domains, width).copy() for table, off, width, _, _ in groups]
-    _RESULTS['used'] = 0
+    out = [buf[off:off + table.n_domains * width].reshape(table.n_domains, width).copy() for table, (buf, off), width, _, _ in groups]
+    _RESULTS.used = 0
     return out
 
 

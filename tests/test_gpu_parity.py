@@ -620,3 +620,26 @@ def test_walk_kernel_widths_and_kept_columns_against_oracle(dd):
             assert ctx.get_option('degenerate_channels') == 3, (D, m)
     finally:
         ctx.set_option('path', 0)
+
+
+def test_result_slots_survive_a_buffer_change_between_layer_groups(dd):
+    """One protein whose layers differ in their row count is enqueued group by group into the pinned result buffer;
+    when the second group does not fit, a new buffer is taken and the first group's slot must still be read from the
+    old one (and stay alive until the stream has been waited for)."""
+    import dctdomain_amd.fingerprint as fpm
+    L, D = 90, 640
+    x0 = make_input('esm', L, D, 9101)
+    x1 = make_input('esm', L + 7, D, 9102)
+    doms = ['1-40', '20-90']
+    warm = dd.Fingerprint(pid='w', seq='A' * L, embed={0: x0}, domains=list(doms))
+    warm.quantize([3, 80])                                    # the thread's buffer exists now
+    st = fpm._RESULTS
+    first = len(doms) * 240
+    st.used = st.pin.numel() - first - 16                     # room for the first group only
+    old = st.pin
+    fp = dd.Fingerprint(pid='t', seq='A' * L, embed={0: x0, 1: x1}, domains=list(doms))
+    fp.quantize([3, 80, 3, 80])
+    assert st.pin is not old
+    for dom in doms:
+        exp = np.concatenate([orc.quantize_matrix([x0], [dom], [3, 80])[dom], orc.quantize_matrix([x1], [dom], [3, 80])[dom]])
+        np.testing.assert_array_equal(fp.quants[dom], exp)
