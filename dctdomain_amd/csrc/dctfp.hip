@@ -209,7 +209,7 @@ struct dctfp_ctx {
     std::unordered_map<uint64_t, double*> basis_tabs;
     size_t basis_doubles = 0;
     unsigned long long* degenerate = nullptr;  // device counter: exactly constant channels seen (see dctfp.h)
-    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0;
+    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     std::map<std::pair<int, int>, StEntry> st_cache;
     uint64_t tick = 0;
@@ -680,6 +680,9 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "ab_unroll") {
         if (value != 0 && value != 4 && value != 6 && value != 8) return fail(DCTFP_ERR_INVALID, "ab_unroll must be 0 (auto), 4, 6 or 8");
         ctx->opt_ab_unroll = value;
+    } else if (n == "small_b_jobs") {
+        if (value < 0 || value > 1 << 20) return fail(DCTFP_ERR_INVALID, "small_b_jobs must be 0 .. 2^20");
+        ctx->opt_small_b_jobs = value;
     } else if (n == "ab_run_jobs") {
         if (value < 0 || value > 4096) return fail(DCTFP_ERR_INVALID, "ab_run_jobs must be 0 (auto) .. 4096");
         ctx->opt_ab_run_jobs = value;
@@ -715,6 +718,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     else if (n == "ab_group") *value = ctx->opt_ab_group;
     else if (n == "ab_unroll") *value = ctx->opt_ab_unroll;
     else if (n == "ab_run_jobs") *value = ctx->opt_ab_run_jobs;
+    else if (n == "small_b_jobs") *value = ctx->opt_small_b_jobs;
     else if (n == "degenerate_channels") {  // synchronises the device
         unsigned long long v = 0;
         HIP_TRY(hipSetDevice(ctx->device));
@@ -1036,10 +1040,11 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             avg_rows = cnt ? rows / cnt : 0;
         }
         std::vector<Chunk> plan;
-        // Y' per job: n float64 rows, or (n = 3 with the MFMA stage B) one float64 t row + one state byte per channel
-        // (a handful of jobs: the MFMA stage B would walk the D channels in 80 dependent steps inside one workgroup --
-        //  ~80 us of latency; the plain kernel, one workgroup per job, is done in a tenth of that)
-        const bool small_b = n_jobs < 32 && ctx->opt_stage_b == 1;
+        // Y' per job: n float64 rows, or (n = 3 with the MFMA stage B) one float64 t row + one state byte per channel.
+        // Below 512 jobs the MFMA stage B (a few workgroups walking the D channels in 80 dependent steps: ~80 us of
+        // latency) loses to stage B over 64-channel slabs (stage_b_slab_kernel): 57 against 147 us at 8 jobs, 195 against
+        // 245 us at 256, even at 512 (profiles/r02/midsize_probe.txt) -- where the walk kernel takes over anyway.
+        const bool small_b = n_jobs < ctx->opt_small_b_jobs && ctx->opt_stage_b == 1;
         const bool packed = ctx->opt_pack_y && n == 3 && ctx->opt_stage_b == 1 && !small_b;
         const size_t job_bytes = packed ? (size_t)ldy_pre * 9 : (size_t)n * ldy_pre * sizeof(double);
         const int n_slabs = (ldy_pre + 64 * vec - 1) / (64 * vec);

@@ -194,6 +194,8 @@ int dctfp_stream_synchronize(void* stream);
  *   "ab_group"     walk kernel: jobs per stage-B flush (0 = auto = 4, 3, 4)
  *   "ab_unroll"    walk kernel: rows in flight per wave (0 = 8; 4, 6, 8)
  *   "ab_run_jobs"  walk kernel: jobs per workgroup (0 = by batch size)
+ *   "small_b_jobs" two-kernel path: calls with fewer jobs (layers x domains) than this run stage B over 64-channel slabs
+ *                  instead of the MFMA kernel (default 512)
  *   "stage_b"      two-kernel path: 0 = plain VALU stage B, 1 = MFMA f64 kernel (default)
  *   "a_waves"      two-kernel path: waves per stage-A workgroup: 0 = by average rows per job (default), 2, 4, 8, 16
  *   "a_unroll"     two-kernel path: rows in flight per wave (4 or 8)

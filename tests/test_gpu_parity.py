@@ -59,9 +59,9 @@ SUBSET = [c for c in ALL_OK if c['id'].startswith(('two_', 'dom_', 'qdim_', 'con
                                   dict(a_waves=16, a_unroll=8), dict(a_waves=4, a_unroll=4),
                                   dict(workspace_mb=16), dict(a_waves=2, a_unroll=8), dict(a_waves=1), dict(overlap=1), dict(fuse=0), dict(pack_y=0),
                                   dict(path=1), dict(path=1, fuse=0), dict(ab_unroll=4), dict(ab_unroll=6), dict(ab_unroll=8), dict(ab_group=3), dict(ab_group=4), dict(path=2), dict(ab_run_jobs=4), dict(ab_run_jobs=64),
-                                  dict(ab_run_jobs=1)],
+                                  dict(ab_run_jobs=1), dict(small_b_jobs=0), dict(path=1, small_b_jobs=1 << 20)],
                          ids=['valuB', 'mfmaB', 'w8u4', 'w16u8', 'w4u4', 'smallws', 'w2u8', 'w1', 'nooverlap', 'nofuse', 'nopack',
-                              'twokernels', 'twokernels_nofuse', 'walk_u4', 'walk_u6', 'walk_u8', 'walk_g3', 'walk_g4', 'walk_forced', 'walk_run4', 'walk_run64', 'walk_run1'])
+                              'twokernels', 'twokernels_nofuse', 'walk_u4', 'walk_u6', 'walk_u8', 'walk_g3', 'walk_g4', 'walk_forced', 'walk_run4', 'walk_run64', 'walk_run1', 'mfmaB_small_calls', 'slabB_always'])
 def test_kernel_variants_agree_with_golden(dd, opts):
     import torch
     ctx = dd.get_context(torch.cuda.current_device())
@@ -643,3 +643,52 @@ def test_result_slots_survive_a_buffer_change_between_layer_groups(dd):
     for dom in doms:
         exp = np.concatenate([orc.quantize_matrix([x0], [dom], [3, 80])[dom], orc.quantize_matrix([x1], [dom], [3, 80])[dom]])
         np.testing.assert_array_equal(fp.quants[dom], exp)
+
+
+def test_midsize_calls_fused_walks_with_both_stage_b_forms(dd):
+    """Between a protein per call and a batch: 60 multi-domain proteins in one call (64 <= jobs < 512: fused stage A, Y'
+    unpacked, stage B over 64-channel slabs) against the oracle, and byte for byte against the MFMA stage B (packed Y')
+    and the unfused form of the same call."""
+    import torch
+    rng = np.random.default_rng(4242)
+    D = 640
+    ctx = dd.get_context(torch.cuda.current_device())
+    lens, doms, xs = [], [], []
+    for s in range(60):
+        L = int(rng.integers(60, 260))
+        k = int(rng.integers(1, 4))
+        if k == 1:
+            d = [f'1-{L}']
+        else:
+            cuts = sorted(set(int(c) for c in rng.integers(22, L - 22, size=k - 1)))
+            e = [0] + cuts + [L]
+            e = [v for i, v in enumerate(e) if i == 0 or v == L or v - e[i - 1] >= 22]
+            if L - e[-2] < 22:
+                e.pop(-2)
+            parts = [f'{a + 1}-{b}' for a, b in zip(e[:-1], e[1:])]
+            d = parts + [f'1-{L}'] if len(parts) > 1 else [f'1-{L}']
+        lens.append(L)
+        doms.append(d)
+        xs.append([make_input('esm', L, D, 88_000 + 2 * s + li) for li in range(2)])
+    table = dd.PieceTable(lens, doms)
+    assert 64 <= 2 * table.n_domains < 512
+    lbs = [dd.LayerBatch([torch.from_numpy(x[li]).cuda() for x in xs], 3, 80) for li in range(2)]
+    saved = {k: ctx.get_option(k) for k in ('small_b_jobs', 'fuse')}
+    try:
+        out = dd.quantize_batch(lbs, table).cpu().numpy()
+        assert ctx.get_option('last_path') == 1
+        ctx.set_option('small_b_jobs', 0)
+        assert (dd.quantize_batch(lbs, table).cpu().numpy() == out).all()
+        ctx.set_option('small_b_jobs', saved['small_b_jobs'])
+        ctx.set_option('fuse', 0)
+        assert (dd.quantize_batch(lbs, table).cpu().numpy() == out).all()
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+    row = 0
+    for s in range(60):
+        for dom in doms[s]:
+            exp = np.concatenate([orc.quantize_matrix([xs[s][li]], [dom], [3, 80])[dom] for li in range(2)])
+            np.testing.assert_array_equal(out[row].astype(np.int64), exp, err_msg=f'seq {s} dom {dom}')
+            row += 1
+    assert row == table.n_domains
