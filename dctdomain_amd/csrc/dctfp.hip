@@ -982,7 +982,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         // since its flush contracts the even and odd halves of the basis apart: 5.3 against 4.9-5.25 TB/s on config 4.
         // A small call (a protein at a time, the reference's calling pattern) is latency-bound: there the two-kernel path,
         // which spreads one job over slabs x 8 waves, finishes first.
-        const bool use_walk = walk_ok && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 512));
+        const bool use_walk = walk_ok && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 256));
         // walks of ALL jobs (walk kernel) -- the two-kernel path builds its walks per chunk below
         int64_t n_walks = 0, n_runs = 0;
         int walk_s = 0, walk_g = 0;
@@ -1011,6 +1011,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             if (want == 0) {
                 want = 2 * walk_g;
                 while (want > walk_g && n_jobs / want < 4096) want -= walk_g;
+                // a few hundred jobs: one or two per workgroup, so that the call spreads over the chip (a flush of one
+                // job costs the MFMAs of four, but the call is latency-bound: 148 against 286 us at 256 jobs)
+                if (n_jobs < 512) want = 1;
+                else if (n_jobs < 768) want = 2;
             }
             for (int64_t w = 0; w < n_walks;) {
                 Run& rn = hrun[n_runs++];
@@ -1043,7 +1047,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         // Y' per job: n float64 rows, or (n = 3 with the MFMA stage B) one float64 t row + one state byte per channel.
         // Below 512 jobs the MFMA stage B (a few workgroups walking the D channels in 80 dependent steps: ~80 us of
         // latency) loses to stage B over 64-channel slabs (stage_b_slab_kernel): 57 against 147 us at 8 jobs, 195 against
-        // 245 us at 256, even at 512 (profiles/r02/midsize_probe.txt) -- where the walk kernel takes over anyway.
+        // 245 us at 256, even at 512 (profiles/r02/midsize_probe.txt); the walk kernel takes over from 256 jobs.
         const bool small_b = n_jobs < ctx->opt_small_b_jobs && ctx->opt_stage_b == 1;
         const bool packed = ctx->opt_pack_y && n == 3 && ctx->opt_stage_b == 1 && !small_b;
         const size_t job_bytes = packed ? (size_t)ldy_pre * 9 : (size_t)n * ldy_pre * sizeof(double);
