@@ -858,30 +858,34 @@ __global__ __launch_bounds__(256) void stage_b_finish_kernel(const double* __res
 }
 
 // ---------------------------------------------------------------------------
-// K3: stage A and stage B in ONE kernel ("walk" kernel; n = 3, m <= 80, float32 rows read as 16 B per lane).
+// K3: stage A and stage B in ONE kernel ("walk" kernel; n = 3, 64 < m <= 80, float32 rows read as 16 B per lane).
 //
 // The two-kernel path sends Y' (9 B per channel and job) through HBM.  That is 0.45 % of the bytes at the headline
 // shape but costs 5 % there and up to 30 % on 25-row domains: writes beside a saturated read stream (DESIGN.md
-// section 4, K1).  Here a workgroup owns ALL channels of its jobs -- wave w streams channels [256 w, 256 w + 256) of
-// every row -- so the scaled channels never leave the CU: they are packed into the wave's own LDS slot, and every
-// G jobs the workgroup contracts the G x 3 rows against the stage-B basis with v_mfma_f64_4x4x4_4b_f64 and
-// writes 240 bytes per job.  What reaches HBM is the int8 result alone.
+// section 4, K1).  Here a workgroup owns ALL channels of its jobs, so the scaled channels never leave the CU: they are
+// packed into the wave's own LDS slot, and every G jobs the workgroup contracts their rows against the stage-B basis
+// with v_mfma_f64_4x4x4_4b_f64 and writes 240 bytes per job.  What reaches HBM is the int8 result alone.
 //
 //   grid  : one workgroup per run = a few consecutive walks (a walk = one job, or the parts of a protein + the
 //           whole protein fed from the same rows, as in stage_a_kernel); the jobs of a run are consecutive.
-//   block : S = ceil(D / 256) waves, no row split: a wave streams every row of its 256 channels, UNROLL rows in
-//           flight, cosines through the scalar cache.  No barrier per job -- the epilogue of a job is wave-private.
-//   flush : every G jobs (or at the end of the run).  v_mfma_f64_4x4x4_4b_f64 (measured 16.8 cycles, 75 TFLOP/s with
-//           8 independent accumulators; tools/microbench/mfma_f64_probe.hip): per block b = (lane >> 2) & 3
+//   block : S = ceil(D / 256) waves, no row split.  Wave w owns the 128 channel PAIRS (d, D-1-d), d in [128 w, 128 w + 128):
+//           lanes 0..31 stream channels [128 w, 128 w + 128) of every row, lanes 32..63 their mirror images (two 512-byte
+//           segments per row), UNROLL rows in flight, cosines through the scalar cache.  No barrier per job -- the
+//           epilogue of a job is wave-private.
+//   flush : every G jobs (or at the end of the run), stage B in even / odd halves (see "flush" in the kernel): with
+//           u = y[d] + y[D-1-d], v = y[d] - y[D-1-d]: ZE[c] = sum u E[d][c], ZO[c] = sum v O[d][c] over the D/2 pairs and
+//           the m/2 left columns, Z[c] = ZE + ZO, Z[m-1-c] = ZE - ZO.  v_mfma_f64_4x4x4_4b_f64 (measured 16.8 cycles,
+//           75 TFLOP/s with 8 independent accumulators; tools/microbench/mfma_f64_probe.hip): per block b = (lane >> 2) & 3
 //               A[i = lane & 3][k = lane >> 4],  B[k = lane >> 4][j = lane & 3],  D[i = lane >> 4][j = lane & 3]
-//           so with the SAME A in the four blocks one instruction multiplies 4 rows (3 used: a job's three resampled
-//           positions) x 4 channels by 4 channels x 16 columns: D lane = Z[row lane >> 4][16 c + (lane & 15)].
-//           Each wave contracts its own 256 channels (K split over the waves); the partial 3 x 80 blocks are summed
-//           through LDS in wave order (deterministic), then per row min / max, scale, x 127, truncate.
-//   stf   : the stage-B basis in fragment order, stf[(((q * 4 + r) * NT + c) * 64 + lane] =
-//           St[16 q + 4 (lane >> 4) + r][16 c + (lane & 15)]  (q = 16-channel group, r = k-step inside it, c = 16-column
-//           group): the B operand of one MFMA is 512 contiguous bytes, the NT operands of a k-step follow each other.
-//           The channel order inside a group (k = 4 (lane >> 4) + r) is the one the packed Y' is read in.
+//           The 4 rows i of a tile are the (up to) 4 jobs of the flush, one tile per resampled position j = 0, 1, 2 and
+//           16-slot group: D lane = Z part of job lane >> 4, slot 16 c + (lane & 15).  Each wave contracts its own 128
+//           pairs (K split over the waves); the partial 3 x 80 blocks are summed through LDS in wave order
+//           (deterministic), then ZE +- ZO, per row min / max, scale, x 127, truncate.
+//   stf   : [E | O] (80 slots: E columns 0..39, O columns 0..39) in fragment order (host: get_st),
+//           stf[((q * 4 + r) * NT + c) * 64 + lane] = Tab[16 q + 4 (lane >> 4) + r][16 c + (lane & 15)]  (q = 16-pair group,
+//           r = k-step inside it, c = 16-slot group): the B operand of one MFMA is 512 contiguous bytes, the NT operands
+//           of a k-step follow each other.  The pair order inside a group (k = 4 (lane >> 4) + r) is the one the packed
+//           Y' is read in.
 // ---------------------------------------------------------------------------
 struct Run {
     uint32_t walk_begin;  // first Walk of this workgroup
