@@ -365,7 +365,7 @@ int basis_lookup(dctfp_ctx* ctx, uint32_t len, int nk, double** out, std::vector
         *out = it->second;
         return DCTFP_OK;
     }
-    const size_t need = align_up((size_t)len * nk, 2);  // 16-byte granules (s_load_dwordx4)
+    const size_t need = align_up((size_t)len * nk + ((size_t)len + 1) * nk, 2);  // cosines + prefix sums; 16-byte granules (s_load_dwordx4)
     if (ctx->basis_slabs.empty() || ctx->basis_slabs.back().used + need > ctx->basis_slabs.back().cap) {
         BasisSlab sl;
         sl.cap = std::max(need, kBasisSlabDoubles);
@@ -1167,7 +1167,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         if (!fresh.empty()) {  // cosine tables this context has not seen yet (grid.y is limited to 65535)
             uint32_t max_len = 0;
             for (const BasisJob& bj : fresh) max_len = std::max(max_len, bj.len);
-            const unsigned gx = (unsigned)std::min<uint64_t>(((uint64_t)max_len * nk + 255) / 256, 1024);
+            const unsigned gx = (unsigned)std::min<uint64_t>(((2 * (uint64_t)max_len + 1) * nk + 255) / 256, 1024);
             for (size_t b0 = 0; b0 < fresh.size(); b0 += 65535) {
                 const unsigned ny = (unsigned)std::min<size_t>(fresh.size() - b0, 65535);
                 hipLaunchKernelGGL(basis_kernel, dim3(gx, ny), dim3(256), 0, ts, dbt + b0, nk);

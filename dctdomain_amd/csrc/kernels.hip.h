@@ -78,7 +78,11 @@ __device__ inline double cospi_ratio(uint64_t p, uint64_t q) {
 
 // ---------------------------------------------------------------------------
 // K0: cosine tables for stage A, one per distinct domain length (filled once per context, then reused by
-// every later call).  Table of length L:   tab[t*NK + (k-1)] = cos(pi k (2t+1) / (2L))
+// every later call).  Table of length L:   tab[t*NK + (k-1)] = cos(pi k (2t+1) / (2L)),  t < L,
+// followed by the prefix sums              pre[t*NK + (k-1)] = sum_{t' < t} cos(pi k (2t'+1) / (2L)),  t <= L
+// (closed form sin(pi k t / L) / (2 sin(pi k / 2L)); pre = tab + L*NK).  The prefix sums let a fused walk accumulate the
+// whole protein against the PART's first row -- one subtraction per element feeds both accumulator sets -- and restore
+// the whole protein's own shift once per part (walk_ab_kernel).
 // ---------------------------------------------------------------------------
 struct BasisJob {
     double* tab;
@@ -86,13 +90,34 @@ struct BasisJob {
     uint32_t reserved;
 };
 
+// sin(pi * p / q) with the argument reduced exactly in integers (q > 0, p >= 0).
+__device__ inline double sinpi_ratio(uint64_t p, uint64_t q) {
+    p %= 2 * q;
+    double sign = 1.0;
+    if (p > q) {
+        p -= q;
+        sign = -1.0;
+    }
+    if (2 * p > q) p = q - p;
+    const double r = (4 * p > q) ? cospi((double)(q - 2 * p) / (double)(2 * q)) : sinpi((double)p / (double)q);
+    return sign * r;
+}
+
 __global__ void basis_kernel(const BasisJob* __restrict__ tabs, int nk) {
     const BasisJob tj = tabs[blockIdx.y];
-    const uint64_t total = (uint64_t)tj.len * nk;
+    const uint64_t n_cos = (uint64_t)tj.len * nk;
+    const uint64_t total = n_cos + ((uint64_t)tj.len + 1) * nk;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t t = i / nk;
-        const uint64_t k = i % nk + 1;
-        tj.tab[i] = cospi_ratio(k * (2 * t + 1), 2 * (uint64_t)tj.len);
+        if (i < n_cos) {
+            const uint64_t t = i / nk;
+            const uint64_t k = i % nk + 1;
+            tj.tab[i] = cospi_ratio(k * (2 * t + 1), 2 * (uint64_t)tj.len);
+        } else {
+            const uint64_t t = (i - n_cos) / nk;
+            const uint64_t k = (i - n_cos) % nk + 1;
+            // (k < 2L always: k <= n - 1 <= L - 1, so the denominator is not zero)
+            tj.tab[i] = sinpi_ratio(k * t, tj.len) / (2.0 * sinpi_ratio(k, 2 * (uint64_t)tj.len));
+        }
     }
 }
 
@@ -949,10 +974,12 @@ __global__ __launch_bounds__(S * 64, DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(c
 #pragma unroll
             for (int k = 0; k < (FUSED ? NK : 1); ++k) wacc[k][v] = 0.0;
         }
+        uint32_t w_rows = 0;  // rows of the whole protein = offset of the prefix sums behind its cosine table
         if (has_w) {
             const Rw w0 = load_raw<float, VEC>(reinterpret_cast<const float*>(jobs[wk.job_begin].w_ref) + colc);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) wref[v] = (double)w0[v];
+            w_rows = jobs[wk.whole_job].n_rows;
         }
 
         for (uint32_t part = 0; part < n_walk_jobs; ++part) {
@@ -974,6 +1001,14 @@ __global__ __launch_bounds__(S * 64, DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(c
                 // The stream of one piece, once with and once without the whole-protein accumulation: the test of `has_w`
                 // must not sit inside the row loop -- a branch per row keeps the whole protein's cosine load (s_load) next
                 // to its use, its latency exposed row after row (that was 20 % of the fused walks).
+                // SINGLE (D > 1280): the whole protein is accumulated against the PART's first row, so that one subtraction
+                // per element feeds both accumulator sets (24 instead of 28 float64 instructions per row and lane), and its
+                // own shift is restored once per part:  sum_t cw(t) (x_t - r_w) = sum_t cw(t) (x_t - r_p) + (r_p - r_w) sum_t cw(t),
+                // the last sum from the prefix sums behind the whole protein's table.  An exactly constant channel still
+                // gives exactly 0: both terms vanish.  Measured (profiles/r02/experiments/single_shift_by_width.log): +1..3 %
+                // with 10 waves per workgroup, +-0 with 5, -2..4 % with 3 -- so only the widest shape uses it.
+                constexpr bool SINGLE = FUSED && S >= 10;
+                double cwsum[NK] = {0.0, 0.0};
                 auto stream_piece = [&](auto hw_tag, const PieceA& piece) {
                     constexpr bool HW = decltype(hw_tag)::value;
                     const float* __restrict__ base = reinterpret_cast<const float*>(piece.ptr) + colc;
@@ -981,17 +1016,14 @@ __global__ __launch_bounds__(S * 64, DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(c
                     const CosTab wtp = cos_tab(job.w_basis) + (size_t)piece.w0 * NK;
                     auto row_update = [&](const Rw& x, uint32_t r) {
                         const CosTab c = btp + (size_t)r * NK;
+                        const CosTab cw = wtp + (size_t)r * NK;
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
                             const double d = (double)x[v] - ref[v];
 #pragma unroll
                             for (int k = 0; k < NK; ++k) f[k][v] = fma(c[k], d, f[k][v]);
-                        }
-                        if constexpr (HW) {
-                            const CosTab cw = wtp + (size_t)r * NK;
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v) {
-                                const double dw = (double)x[v] - wref[v];
+                            if constexpr (HW) {
+                                const double dw = SINGLE ? d : (double)x[v] - wref[v];
 #pragma unroll
                                 for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(cw[k], dw, wacc[FUSED ? k : 0][v]);
                             }
@@ -1024,11 +1056,24 @@ __global__ __launch_bounds__(S * 64, DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(c
                         for (int u = 0; u < 3; ++u)
                             if (r + u < piece.n_rows) row_update(xv[u], r + u);
                     }
+                    if constexpr (HW && SINGLE) {  // prefix sums past this piece's last and at its first row
+                        const CosTab wpre = wtp + (size_t)w_rows * NK;
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) cwsum[k] += wpre[(size_t)piece.n_rows * NK + k] - wpre[k];
+                    }
                 };
                 for (uint32_t p = 0; p < job.n_pieces; ++p) {
                     const PieceA piece = pc[p];
                     if (FUSED && has_w) stream_piece(std::integral_constant<bool, FUSED>{}, piece);
                     else stream_piece(std::false_type{}, piece);
+                }
+                if (SINGLE && has_w) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const double dr = ref[v] - wref[v];
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(dr, cwsum[k], wacc[FUSED ? k : 0][v]);
+                    }
                 }
             } else {
 #pragma unroll
