@@ -930,7 +930,7 @@ constexpr int kWalkChannels = 256;  // channels per wave: 64 lanes x 4 float32
 #endif                               // what a flush costs is issue time, not L2 latency (profiles/r02/experiments/flush_*)
 
 template <int S, int G, int NT, int UNROLL, bool FUSED>
-__global__ __launch_bounds__(S * 64, DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
+__global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
                                                           const Walk* __restrict__ walks, const Run* __restrict__ runs,
                                                           const PieceA* __restrict__ pieces, const double* __restrict__ stf,
                                                           int8_t* __restrict__ out, int n_cols, int64_t ld, int m,
