@@ -209,6 +209,7 @@ struct dctfp_ctx {
     std::unordered_map<uint64_t, double*> basis_tabs;
     size_t basis_doubles = 0;
     unsigned long long* degenerate = nullptr;  // device counter: exactly constant channels seen (see dctfp.h)
+    int n_cu = 256;  // compute units of the device (workgroup slots of the walk kernel = n_cu x workgroups per CU)
     int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     std::map<std::pair<int, int>, StEntry> st_cache;
@@ -605,6 +606,7 @@ int dctfp_create(int device, dctfp_ctx** out) {
     dctfp_ctx* ctx = new (std::nothrow) dctfp_ctx();
     if (!ctx) return fail(DCTFP_ERR_NOMEM, "dctfp_create: out of host memory");
     ctx->device = device;
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t e = hipMalloc((void**)&ctx->degenerate, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->degenerate, 0, sizeof(unsigned long long));
     if (e != hipSuccess) {
@@ -1009,12 +1011,27 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             // flushes are full); fewer jobs per run when the batch is small, to keep every CU busy
             int64_t want = ctx->opt_ab_run_jobs;
             if (want == 0) {
-                want = 2 * walk_g;
-                while (want > walk_g && n_jobs / want < 4096) want -= walk_g;
-                // a few hundred jobs: one or two per workgroup, so that the call spreads over the chip (a flush of one
-                // job costs the MFMAs of four, but the call is latency-bound: 148 against 286 us at 256 jobs)
-                if (n_jobs < 512) want = 1;
-                else if (n_jobs < 768) want = 2;
+                // Rows per job decide (profiles/r02/path_probe_run_jobs.log): long jobs (whole proteins) want ONE per
+                // workgroup -- a flush of one job costs the MFMAs of four, nothing beside 500 rows, and 4 x as many, smaller
+                // workgroups drain the chip more evenly at the end (C2 6.79 -> 6.97 TB/s, C3 6.70 -> 6.90); short jobs
+                // (domains) want many per workgroup, so that few flushes are partial (c4 5.80 -> 5.91 at 16).
+                int64_t rows = 0;
+                for (int64_t d = 0; d < n_domains; ++d)
+                    if (!(fuse && is_whole[d])) rows += dom_len[d];
+                const int64_t job_rows = rows / std::max<int64_t>(1, n_domains);  // whole-protein jobs of fused walks stream nothing
+                const int64_t by_rows = job_rows >= 384 ? 1 : (job_rows >= 192 ? 2 : 4 * walk_g);
+                // workgroups the chip holds at once (LDS: 5 / 3 / 1 per CU at 3 / 5 / 10 waves)
+                const int64_t slots = (int64_t)ctx->n_cu * (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));
+                if (n_jobs <= 6 * slots * by_rows) {
+                    // fewer than a handful of rounds at that size: ONE round of equal workgroups instead (a second, partly
+                    // filled round costs as much as a full one: 1 024 whole-protein jobs 509 us as 1 024 workgroups, 477 as 512)
+                    want = std::max<int64_t>(1, (n_jobs + slots - 1) / slots);
+                    if (by_rows >= walk_g && want > 1) want = (want + walk_g - 1) / walk_g * walk_g;  // short jobs: full flushes
+                    want = std::min<int64_t>(want, 4 * walk_g);
+                } else {
+                    want = by_rows;
+                    while (want > walk_g && n_jobs / want < 8192) want -= walk_g;  // ... but ten rounds of workgroups at least
+                }
             }
             for (int64_t w = 0; w < n_walks;) {
                 Run& rn = hrun[n_runs++];
