@@ -210,7 +210,7 @@ struct dctfp_ctx {
     size_t basis_doubles = 0;
     unsigned long long* degenerate = nullptr;  // device counter: exactly constant channels seen (see dctfp.h)
     int n_cu = 256;  // compute units of the device (workgroup slots of the walk kernel = n_cu x workgroups per CU)
-    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512;
+    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     std::map<std::pair<int, int>, StEntry> st_cache;
     uint64_t tick = 0;
@@ -685,6 +685,9 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "small_b_jobs") {
         if (value < 0 || value > 1 << 20) return fail(DCTFP_ERR_INVALID, "small_b_jobs must be 0 .. 2^20");
         ctx->opt_small_b_jobs = value;
+    } else if (n == "ab_longest_first") {
+        if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "ab_longest_first must be 0 (auto), 1 (on) or 2 (off)");
+        ctx->opt_ab_longest_first = value;
     } else if (n == "ab_run_jobs") {
         if (value < 0 || value > 4096) return fail(DCTFP_ERR_INVALID, "ab_run_jobs must be 0 (auto) .. 4096");
         ctx->opt_ab_run_jobs = value;
@@ -720,6 +723,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     else if (n == "ab_group") *value = ctx->opt_ab_group;
     else if (n == "ab_unroll") *value = ctx->opt_ab_unroll;
     else if (n == "ab_run_jobs") *value = ctx->opt_ab_run_jobs;
+    else if (n == "ab_longest_first") *value = ctx->opt_ab_longest_first;
     else if (n == "small_b_jobs") *value = ctx->opt_small_b_jobs;
     else if (n == "degenerate_channels") {  // synchronises the device
         unsigned long long v = 0;
@@ -1010,6 +1014,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             // runs: consecutive walks until a run holds `want` jobs (a multiple of the flush group, so that most
             // flushes are full); fewer jobs per run when the batch is small, to keep every CU busy
             int64_t want = ctx->opt_ab_run_jobs;
+            bool longest_first = ctx->opt_ab_longest_first == 1;
             if (want == 0) {
                 // Rows per job decide (profiles/r02/path_probe_run_jobs.log): long jobs (whole proteins) want ONE per
                 // workgroup -- a flush of one job costs the MFMAs of four, nothing beside 500 rows, and 4 x as many, smaller
@@ -1020,6 +1025,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                     if (!(fuse && is_whole[d])) rows += dom_len[d];
                 const int64_t job_rows = rows / std::max<int64_t>(1, n_domains);  // whole-protein jobs of fused walks stream nothing
                 const int64_t by_rows = job_rows >= 384 ? 1 : (job_rows >= 192 ? 2 : 4 * walk_g);
+                if (ctx->opt_ab_longest_first == 0) longest_first = by_rows >= walk_g && walk_s == 10;
                 // workgroups the chip holds at once (LDS: 5 / 3 / 1 per CU at 3 / 5 / 10 waves)
                 const int64_t slots = (int64_t)ctx->n_cu * (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));
                 if (n_jobs <= 6 * slots * by_rows) {
@@ -1044,6 +1050,26 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 }
                 rn.n_walks = (uint32_t)(w - rn.walk_begin);
                 rn.n_jobs = jobs_in;
+            }
+            // Longest run first, for batches of domains at D > 1280 (one workgroup per CU: 256 slots, so the last round
+            // weighs most): the workgroups that start last are the short ones and the chip drains together (c4 +2.8 %).
+            // With 1 280 slots (D = 640) it gains nothing in the kernel and costs 70 us of host time per 340 000 jobs; on
+            // whole-protein batches it would put every short protein -- the jobs whose flush weighs most -- at the end
+            // together (C3 -1.5 %).  Counting sort on the rows a run streams, 16-row buckets, input order within a bucket.
+            if (longest_first && n_runs > 1) {
+                constexpr uint32_t kBuckets = 4096;
+                std::vector<uint32_t> key((size_t)n_runs), start(kBuckets + 1, 0);
+                for (int64_t r = 0; r < n_runs; ++r) {
+                    uint64_t rows = 0;
+                    for (uint32_t w = hrun[r].walk_begin; w < hrun[r].walk_begin + hrun[r].n_walks; ++w)
+                        for (uint32_t p = 0; p < hwalk[w].n_parts; ++p) rows += (uint64_t)dom_len[(hwalk[w].job_begin + p) % n_domains];
+                    key[r] = kBuckets - 1 - (uint32_t)std::min<uint64_t>(rows >> 4, kBuckets - 1);  // descending
+                    ++start[key[r] + 1];
+                }
+                for (uint32_t b = 0; b < kBuckets; ++b) start[b + 1] += start[b];
+                std::vector<Run> sorted((size_t)n_runs);
+                for (int64_t r = 0; r < n_runs; ++r) sorted[start[key[r]]++] = hrun[r];
+                std::memcpy(hrun, sorted.data(), (size_t)n_runs * sizeof(Run));
             }
         }
 

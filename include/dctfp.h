@@ -194,6 +194,8 @@ int dctfp_stream_synchronize(void* stream);
  *   "ab_group"     walk kernel: jobs per stage-B flush (0 = auto = 4, 3, 4)
  *   "ab_unroll"    walk kernel: rows in flight per wave (0 = 8; 4, 6, 8)
  *   "ab_run_jobs"  walk kernel: jobs per workgroup (0 = by batch size)
+ *   "ab_longest_first" walk kernel: workgroups ordered by the rows they stream, longest first (0 = auto: batches of
+ *                  domains at D > 1280, 1 = always, 2 = never)
  *   "small_b_jobs" two-kernel path: calls with fewer jobs (layers x domains) than this run stage B over 64-channel slabs
  *                  instead of the MFMA kernel (default 512)
  *   "stage_b"      two-kernel path: 0 = plain VALU stage B, 1 = MFMA f64 kernel (default)

@@ -12,7 +12,7 @@ dev = torch.device('cuda', 0)
 ctx = dd.get_context(0)
 args_w = [a for a in sys.argv[1:] if not a.startswith('--') and '=' not in a] or ['c2', 'c4', 'c5']
 cfgs = [a for a in sys.argv[1:] if '=' in a] or ['path=1', 'path=2', 'path=2,ab_unroll=4']
-defaults = {k: ctx.get_option(k) for k in ('path', 'ab_group', 'ab_unroll', 'ab_run_jobs', 'overlap', 'a_waves', 'fuse')}
+defaults = {k: ctx.get_option(k) for k in ('path', 'ab_group', 'ab_unroll', 'ab_run_jobs', 'ab_longest_first', 'overlap', 'a_waves', 'fuse')}
 nseq = {'c2': 10000, 'c3': 10000, 'c4': 12000, 'c5': 40000}
 for w in args_w:
     argv, sys.argv = sys.argv, ['bench.py', '--workload', w, '--n-seq', str(nseq[w])]
