@@ -967,20 +967,12 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
         const bool has_w = FUSED && wk.whole_job >= 0;
         const uint32_t n_walk_jobs = wk.n_parts + (has_w ? 1u : 0u);
         double wacc[FUSED ? NK : 1][VEC];
-        double wref[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            wref[v] = 0.0;
+        for (int v = 0; v < VEC; ++v)
 #pragma unroll
             for (int k = 0; k < (FUSED ? NK : 1); ++k) wacc[k][v] = 0.0;
-        }
-        uint32_t w_rows = 0;  // rows of the whole protein = offset of the prefix sums behind its cosine table
-        if (has_w) {
-            const Rw w0 = load_raw<float, VEC>(reinterpret_cast<const float*>(jobs[wk.job_begin].w_ref) + colc);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) wref[v] = (double)w0[v];
-            w_rows = jobs[wk.whole_job].n_rows;
-        }
+        // rows of the whole protein = offset of the prefix sums behind its cosine table
+        const uint32_t w_rows = has_w ? jobs[wk.whole_job].n_rows : 0u;
 
         for (uint32_t part = 0; part < n_walk_jobs; ++part) {
             double f[NK][VEC];
@@ -1001,13 +993,13 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 // The stream of one piece, once with and once without the whole-protein accumulation: the test of `has_w`
                 // must not sit inside the row loop -- a branch per row keeps the whole protein's cosine load (s_load) next
                 // to its use, its latency exposed row after row (that was 20 % of the fused walks).
-                // SINGLE (D > 1280): the whole protein is accumulated against the PART's first row, so that one subtraction
-                // per element feeds both accumulator sets (24 instead of 28 float64 instructions per row and lane), and its
-                // own shift is restored once per part:  sum_t cw(t) (x_t - r_w) = sum_t cw(t) (x_t - r_p) + (r_p - r_w) sum_t cw(t),
-                // the last sum from the prefix sums behind the whole protein's table.  An exactly constant channel still
-                // gives exactly 0: both terms vanish.  Measured (profiles/r02/experiments/single_shift_by_width.log): +1..3 %
-                // with 10 waves per workgroup, +-0 with 5, -2..4 % with 3 -- so only the widest shape uses it.
-                constexpr bool SINGLE = FUSED && S >= 10;
+                // The whole protein is accumulated against the PART's first row, so that one subtraction per element feeds
+                // both accumulator sets (24 instead of 28 float64 instructions per row and lane), and its own shift is
+                // restored once per part:  sum_t cw(t) (x_t - r_w) = sum_t cw(t) (x_t - r_p) + (r_p - r_w) sum_t cw(t),
+                // the last sum from the prefix sums behind the whole protein's table, r_w read again at the end of the part
+                // (kept in registers through the stream it cost 5 more spilled registers per lane: the scratch WRITES beside
+                // the row stream made the variant 3 % slower at D <= 1280 although it issues 9 % fewer instructions -- PMC:
+                // profiles/r02/pmc_single_shift_*.md).  An exactly constant channel still gives exactly 0: both terms vanish.
                 double cwsum[NK] = {0.0, 0.0};
                 auto stream_piece = [&](auto hw_tag, const PieceA& piece) {
                     constexpr bool HW = decltype(hw_tag)::value;
@@ -1023,9 +1015,8 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
 #pragma unroll
                             for (int k = 0; k < NK; ++k) f[k][v] = fma(c[k], d, f[k][v]);
                             if constexpr (HW) {
-                                const double dw = SINGLE ? d : (double)x[v] - wref[v];
 #pragma unroll
-                                for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(cw[k], dw, wacc[FUSED ? k : 0][v]);
+                                for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(cw[k], d, wacc[FUSED ? k : 0][v]);
                             }
                         }
                     };
@@ -1056,7 +1047,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                         for (int u = 0; u < 3; ++u)
                             if (r + u < piece.n_rows) row_update(xv[u], r + u);
                     }
-                    if constexpr (HW && SINGLE) {  // prefix sums past this piece's last and at its first row
+                    if constexpr (HW) {  // prefix sums past this piece's last and at its first row
                         const CosTab wpre = wtp + (size_t)w_rows * NK;
 #pragma unroll
                         for (int k = 0; k < NK; ++k) cwsum[k] += wpre[(size_t)piece.n_rows * NK + k] - wpre[k];
@@ -1067,10 +1058,11 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                     if (FUSED && has_w) stream_piece(std::integral_constant<bool, FUSED>{}, piece);
                     else stream_piece(std::false_type{}, piece);
                 }
-                if (SINGLE && has_w) {
+                if (FUSED && has_w) {
+                    const Rw w0 = load_raw<float, VEC>(reinterpret_cast<const float*>(job.w_ref) + colc);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
-                        const double dr = ref[v] - wref[v];
+                        const double dr = ref[v] - (double)w0[v];
 #pragma unroll
                         for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(dr, cwsum[k], wacc[FUSED ? k : 0][v]);
                     }
