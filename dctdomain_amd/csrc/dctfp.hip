@@ -470,9 +470,11 @@ void launch_a(const AParams& p, int dtype, int vec, int n, int waves, int unroll
         else launch_a_n<float, 1>(p, n, waves, unroll);
     } else if (dtype == DCTFP_F16) {
         if (vec == 8) launch_a_n<_Float16, 8>(p, n, waves, unroll);
+        else if (vec == 4) launch_a_cfg<_Float16, 3, 4>(p, waves, unroll);  // (n = 3 fused walks only)
         else launch_a_n<_Float16, 1>(p, n, waves, unroll);
     } else if (dtype == DCTFP_BF16) {
         if (vec == 8) launch_a_n<bf16_t, 8>(p, n, waves, unroll);
+        else if (vec == 4) launch_a_cfg<bf16_t, 3, 4>(p, waves, unroll);
         else launch_a_n<bf16_t, 1>(p, n, waves, unroll);
     } else {
         if (vec == 2) launch_a_n<double, 2>(p, n, waves, unroll);
@@ -977,7 +979,11 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         }
         const int vec_want = (int)(16 / esz);  // 16 bytes per lane
         if (((size_t)g.ld * esz) % 16 != 0 || g.n_cols % vec_want != 0) vec_ok = false;
-        const int vec = vec_ok ? vec_want : 1;
+        int vec = vec_ok ? vec_want : 1;
+        // Fused walks of half-precision rows: 8 channels per lane mean two accumulator sets of 8 -- 27..37 registers per lane
+        // spilled, and scratch writes beside the row stream cost far more than their bytes (the c5 mix in float16 took 19 ms
+        // against 12.6 in float32).  4 channels per lane (8-byte loads) fit the registers.
+        if (fuse && n == 3 && vec == 8) vec = 4;
 
         // ---- which kernels.  The walk kernel (stage A + B in one launch, nothing but int8 written) takes the
         // production shapes: n = 3, 64 < m <= 80 (five 16-column groups), float32 rows read 16 B per lane, 512 <= D <= 2560, no giant domain

@@ -24,6 +24,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+typedef unsigned short v4us __attribute__((ext_vector_type(4)));
 typedef unsigned short v8us __attribute__((ext_vector_type(8)));
 
 // Cosine tables are read-only for the kernels and always addressed wave-uniformly: a constant-address-space view lets the
@@ -136,9 +138,13 @@ struct Raw<double, 1> { typedef double type; };
 template <>
 struct Raw<_Float16, 8> { typedef v8h type; };
 template <>
+struct Raw<_Float16, 4> { typedef v4h type; };  // 8 bytes per lane: fused walks of half-precision rows (register budget)
+template <>
 struct Raw<_Float16, 1> { typedef _Float16 type; };
 template <>
 struct Raw<bf16_t, 8> { typedef v8us type; };
+template <>
+struct Raw<bf16_t, 4> { typedef v4us type; };
 template <>
 struct Raw<bf16_t, 1> { typedef unsigned short type; };
 

@@ -692,3 +692,40 @@ def test_midsize_calls_fused_walks_with_both_stage_b_forms(dd):
             np.testing.assert_array_equal(out[row].astype(np.int64), exp, err_msg=f'seq {s} dom {dom}')
             row += 1
     assert row == table.n_domains
+
+
+@pytest.mark.parametrize('tdtype', ['float16', 'bfloat16'])
+def test_half_precision_fused_walks(dd, tdtype):
+    """Multi-domain proteins in half precision in one call large enough to be fused (>= 64 jobs: the parts and the whole
+    protein fed from the same rows; 4 channels per lane for half-precision rows): against the oracle on the same values
+    promoted to float32, and byte for byte against the unfused form."""
+    import torch
+    dt = getattr(torch, tdtype)
+    rng = np.random.default_rng(77)
+    ctx = dd.get_context(torch.cuda.current_device())
+    for D in (640, 1000):
+        lens, doms, xs = [], [], []
+        for s in range(14):
+            L = int(rng.integers(90, 240))
+            c1, c2 = int(L * 0.3), int(L * 0.62)
+            d = [f'1-{c1}', f'{c1 + 1}-{c2}', f'{c2 + 1}-{L}', f'1-{L}'] if s % 3 else [f'{c2 + 1}-{L},1-{c1}', f'{c1 + 1}-{c2}', f'1-{L}']
+            lens.append(L)
+            doms.append(d)
+            xs.append([torch.from_numpy(make_input('esm', L, D, 41_000 + 2 * s + li)).to(dt).cuda() for li in range(2)])
+        table = dd.PieceTable(lens, doms)
+        assert 2 * table.n_domains >= 64
+        lbs = [dd.LayerBatch([x[li] for x in xs], 3, 80) for li in range(2)]
+        out = dd.quantize_batch(lbs, table).cpu().numpy()
+        ctx.set_option('fuse', 0)
+        try:
+            assert (dd.quantize_batch(lbs, table).cpu().numpy() == out).all()
+        finally:
+            ctx.set_option('fuse', 1)
+        row = 0
+        for s in range(len(lens)):
+            ls = [xs[s][li].float().cpu().numpy() for li in range(2)]
+            for dom in doms[s]:
+                exp = np.concatenate([orc.quantize_matrix([ls[li]], [dom], [3, 80])[orc.split_domain(dom, lens[s])[1]] for li in range(2)])
+                np.testing.assert_array_equal(out[row].astype(np.int64), exp, err_msg=f'{tdtype} D={D} seq {s} {dom}')
+                row += 1
+        assert row == table.n_domains
