@@ -529,29 +529,36 @@ struct WParams {
     hipStream_t stream;
 };
 
-template <int S, int G, int NT, int UNROLL>
+template <typename T, int S, int G, int NT, int UNROLL>
 void launch_walk_impl(const WParams& p, bool fused) {
     static const InvTab<3> inv = make_inv<3>();
     if (fused)
-        hipLaunchKernelGGL((walk_ab_kernel<S, G, NT, UNROLL, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
+        hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
                            p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
     else
-        hipLaunchKernelGGL((walk_ab_kernel<S, G, NT, UNROLL, false>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
+        hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, false>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
                            p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
 }
 
 template <int S, int G>
 int launch_walk_u(const WParams& p, int unroll, bool fused) {
-    if (unroll == 4) launch_walk_impl<S, G, 5, 4>(p, fused);
-    else if (unroll == 6) launch_walk_impl<S, G, 5, 6>(p, fused);
-    else launch_walk_impl<S, G, 5, 8>(p, fused);
+    if (unroll == 4) launch_walk_impl<float, S, G, 5, 4>(p, fused);
+    else if (unroll == 6) launch_walk_impl<float, S, G, 5, 6>(p, fused);
+    else launch_walk_impl<float, S, G, 5, 8>(p, fused);
     return DCTFP_OK;
 }
 
 // Instantiated shapes: S waves cover up to 256 S channels; G = jobs per flush <= 4 (the rows of an MFMA tile), bounded by
 // the LDS too (2304 B per wave and job: G = 4 leaves room for 17 waves per CU, G = 3 for 23).  A flush costs the same
-// MFMAs for 1..4 jobs, so G = 4 is the default everywhere.
-int launch_walk(const WParams& p, int s, int g, int unroll, bool fused) {
+// MFMAs for 1..4 jobs, so G = 4 is the default everywhere.  Half-precision rows: the default shape only.
+int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fused) {
+    if (dtype == DCTFP_F16 || dtype == DCTFP_BF16) {
+        const bool h = dtype == DCTFP_F16;
+        if (s == 3) h ? launch_walk_impl<_Float16, 3, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 3, 4, 5, 8>(p, fused);
+        else if (s == 5) h ? launch_walk_impl<_Float16, 5, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 5, 4, 5, 8>(p, fused);
+        else h ? launch_walk_impl<_Float16, 10, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 10, 4, 5, 8>(p, fused);
+        return DCTFP_OK;
+    }
     if (s == 3 && g == 4) return launch_walk_u<3, 4>(p, unroll, fused);
     if (s == 3 && g == 3) return launch_walk_u<3, 3>(p, unroll, fused);
     if (s == 5 && g == 4) return launch_walk_u<5, 4>(p, unroll, fused);
@@ -988,7 +995,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         // ---- which kernels.  The walk kernel (stage A + B in one launch, nothing but int8 written) takes the
         // production shapes: n = 3, 64 < m <= 80 (five 16-column groups), float32 rows read 16 B per lane, 512 <= D <= 2560, no giant domain
         // (a wave streams all rows of its channels).  Everything else runs stage A -> Y' -> stage B.
-        const bool walk_ok = !trivial && n == 3 && m > 64 && m <= 80 && g.dtype == DCTFP_F32 && vec == 4 && g.n_cols >= 512 &&
+        const bool half_rows = g.dtype == DCTFP_F16 || g.dtype == DCTFP_BF16;  // (their `vec` is 8, or 4 for fused walks: the walk kernel reads 4)
+        const bool walk_ok = !trivial && n == 3 && m > 64 && m <= 80 && ((g.dtype == DCTFP_F32 && vec == 4) || (half_rows && vec >= 4)) && g.n_cols >= 512 &&
                              g.n_cols <= 2560 && max_len_all <= 8192 && ctx->opt_stage_b == 1;
         // Measured (profiles/r02): the walk kernel wins at every width it takes -- D = 2560 (10-wave workgroups, one per CU)
         // since its flush contracts the even and odd halves of the basis apart: 5.3 against 4.9-5.25 TB/s on config 4.
@@ -1029,8 +1037,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 int64_t rows = 0;
                 for (int64_t d = 0; d < n_domains; ++d)
                     if (!(fuse && is_whole[d])) rows += dom_len[d];
-                const int64_t job_rows = rows / std::max<int64_t>(1, n_domains);  // whole-protein jobs of fused walks stream nothing
-                const int64_t by_rows = job_rows >= 384 ? 1 : (job_rows >= 192 ? 2 : 4 * walk_g);
+                // (rows of 4-byte elements: a half-precision job of 500 rows weighs like 250 -- 4.40 ms per C2 batch with four
+                //  jobs per workgroup, 4.85 with one)
+                const int64_t job_rows = rows * (int64_t)esz / 4 / std::max<int64_t>(1, n_domains);  // whole-protein jobs of fused walks stream nothing
+                const int64_t by_rows = job_rows >= 384 ? 1 : 4 * walk_g;
                 if (ctx->opt_ab_longest_first == 0) longest_first = by_rows >= walk_g && walk_s == 10;
                 // workgroups the chip holds at once (LDS: 5 / 3 / 1 per CU at 3 / 5 / 10 waves)
                 const int64_t slots = (int64_t)ctx->n_cu * (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));
@@ -1255,7 +1265,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             wp.degenerate = ctx->degenerate;
             wp.grid = (unsigned)n_runs;
             wp.stream = stream;
-            rc = launch_walk(wp, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : 8, fuse);
+            rc = launch_walk(wp, g.dtype, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : 8, fuse);
             if (rc) return rc;
             HIP_TRY(hipGetLastError());
             rc = prof_end(ep, stream);

@@ -889,7 +889,8 @@ __global__ __launch_bounds__(256) void stage_b_finish_kernel(const double* __res
 }
 
 // ---------------------------------------------------------------------------
-// K3: stage A and stage B in ONE kernel ("walk" kernel; n = 3, 64 < m <= 80, float32 rows read as 16 B per lane).
+// K3: stage A and stage B in ONE kernel ("walk" kernel; n = 3, 64 < m <= 80; 4 channels per lane: float32 rows read as
+// 16 B per lane, float16 / bfloat16 rows as 8 B).
 //
 // The two-kernel path sends Y' (9 B per channel and job) through HBM.  That is 0.45 % of the bytes at the headline
 // shape but costs 5 % there and up to 30 % on 25-row domains: writes beside a saturated read stream (DESIGN.md
@@ -935,7 +936,7 @@ constexpr int kWalkChannels = 256;  // channels per wave: 64 lanes x 4 float32
 #define DCTFP_WALK_B_DEPTH 1         // k-steps of stage-B fragments in flight during a flush (1, 2, 4); more was never faster:
 #endif                               // what a flush costs is issue time, not L2 latency (profiles/r02/experiments/flush_*)
 
-template <int S, int G, int NT, int UNROLL, bool FUSED>
+template <typename T, int S, int G, int NT, int UNROLL, bool FUSED>
 __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
                                                           const Walk* __restrict__ walks, const Run* __restrict__ runs,
                                                           const PieceA* __restrict__ pieces, const double* __restrict__ stf,
@@ -963,7 +964,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
     auto channel_counts = [&](int v) { return !pad && pair0 + (mirror ? VEC - 1 - v : v) < half; };
     // 16-pair groups of this wave that hold real pairs
     const int n_q = min(kWalkChannels / 32, max(0, (half + 15) / 16 - wave * (kWalkChannels / 32)));
-    typedef v4f Rw;
+    typedef typename Raw<T, 4>::type Rw;  // 4 channels per lane: 16 bytes of float32, 8 of float16 / bfloat16
 
     uint32_t pending = 0;            // jobs whose Y' sits in LDS
     uint32_t group_job = run.job_begin;  // job of slot 0
@@ -992,9 +993,9 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) f[k][v] = 0.0;
                 {
-                    const Rw r0 = load_raw<float, VEC>(reinterpret_cast<const float*>(pc[0].ptr) + colc);
+                    const Rw r0 = load_raw<T, VEC>(reinterpret_cast<const T*>(pc[0].ptr) + colc);
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) ref[v] = (double)r0[v];
+                    for (int v = 0; v < VEC; ++v) ref[v] = raw_elem<T, VEC>(r0, v);
                 }
                 // The stream of one piece, once with and once without the whole-protein accumulation: the test of `has_w`
                 // must not sit inside the row loop -- a branch per row keeps the whole protein's cosine load (s_load) next
@@ -1009,7 +1010,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 double cwsum[NK] = {0.0, 0.0};
                 auto stream_piece = [&](auto hw_tag, const PieceA& piece) {
                     constexpr bool HW = decltype(hw_tag)::value;
-                    const float* __restrict__ base = reinterpret_cast<const float*>(piece.ptr) + colc;
+                    const T* __restrict__ base = reinterpret_cast<const T*>(piece.ptr) + colc;
                     const CosTab btp = cos_tab(job.basis) + (size_t)piece.t0 * NK;
                     const CosTab wtp = cos_tab(job.w_basis) + (size_t)piece.w0 * NK;
                     auto row_update = [&](const Rw& x, uint32_t r) {
@@ -1017,7 +1018,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                         const CosTab cw = wtp + (size_t)r * NK;
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
-                            const double d = (double)x[v] - ref[v];
+                            const double d = raw_elem<T, VEC>(x, v) - ref[v];
 #pragma unroll
                             for (int k = 0; k < NK; ++k) f[k][v] = fma(c[k], d, f[k][v]);
                             if constexpr (HW) {
@@ -1030,7 +1031,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                     for (; r + UNROLL <= piece.n_rows; r += UNROLL) {
                         Rw xv[UNROLL];
 #pragma unroll
-                        for (int u = 0; u < UNROLL; ++u) xv[u] = load_raw<float, VEC>(base + (size_t)(r + u) * ld);
+                        for (int u = 0; u < UNROLL; ++u) xv[u] = load_raw<T, VEC>(base + (size_t)(r + u) * ld);
 #pragma unroll
                         for (int u = 0; u < UNROLL; ++u) row_update(xv[u], r + u);
                     }
@@ -1038,7 +1039,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                         if (r + 4 <= piece.n_rows) {
                             Rw xv[4];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) xv[u] = load_raw<float, VEC>(base + (size_t)(r + u) * ld);
+                            for (int u = 0; u < 4; ++u) xv[u] = load_raw<T, VEC>(base + (size_t)(r + u) * ld);
 #pragma unroll
                             for (int u = 0; u < 4; ++u) row_update(xv[u], r + u);
                             r += 4;
@@ -1048,7 +1049,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                         Rw xv[3];
 #pragma unroll
                         for (int u = 0; u < 3; ++u)
-                            if (r + u < piece.n_rows) xv[u] = load_raw<float, VEC>(base + (size_t)(r + u) * ld);
+                            if (r + u < piece.n_rows) xv[u] = load_raw<T, VEC>(base + (size_t)(r + u) * ld);
 #pragma unroll
                         for (int u = 0; u < 3; ++u)
                             if (r + u < piece.n_rows) row_update(xv[u], r + u);
@@ -1065,10 +1066,10 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                     else stream_piece(std::false_type{}, piece);
                 }
                 if (FUSED && has_w) {
-                    const Rw w0 = load_raw<float, VEC>(reinterpret_cast<const float*>(job.w_ref) + colc);
+                    const Rw w0 = load_raw<T, VEC>(reinterpret_cast<const T*>(job.w_ref) + colc);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
-                        const double dr = ref[v] - (double)w0[v];
+                        const double dr = ref[v] - raw_elem<T, VEC>(w0, v);
 #pragma unroll
                         for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(dr, cwsum[k], wacc[FUSED ? k : 0][v]);
                     }

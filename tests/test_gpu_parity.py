@@ -729,3 +729,39 @@ def test_half_precision_fused_walks(dd, tdtype):
                 np.testing.assert_array_equal(out[row].astype(np.int64), exp, err_msg=f'{tdtype} D={D} seq {s} {dom}')
                 row += 1
         assert row == table.n_domains
+
+
+@pytest.mark.parametrize('tdtype', ['float16', 'bfloat16'])
+def test_walk_kernel_on_half_precision_rows(dd, tdtype):
+    """The walk kernel reads float16 / bfloat16 rows as 8 bytes per lane (4 channels, like float32): forced (path=2) on
+    small batches of whole proteins and of fused multi-domain proteins at the three wave counts, against the oracle on the
+    same values promoted to float32."""
+    import torch
+    dt = getattr(torch, tdtype)
+    rng = np.random.default_rng(515)
+    ctx = dd.get_context(torch.cuda.current_device())
+    try:
+        ctx.set_option('path', 2)
+        for D, m in ((640, 80), (1000, 75), (1280, 80), (2560, 72)):
+            lens, doms, xs = [], [], []
+            for s in range(5):
+                L = int(rng.integers(60, 200))
+                if s % 2:
+                    c = int(L * 0.45)
+                    doms.append([f'1-{c}', f'{c + 1}-{L}', f'1-{L}'])
+                else:
+                    doms.append([f'1-{L}'])
+                lens.append(L)
+                xs.append(torch.from_numpy(make_input('esm', L, D, 61_000 + 10 * s + D)).to(dt).cuda())
+            out = dd.quantize_batch([dd.LayerBatch(xs, 3, m)], dd.PieceTable(lens, doms)).cpu().numpy()
+            assert ctx.get_option('last_path') == 2, (D, m)
+            row = 0
+            for s in range(5):
+                x = xs[s].float().cpu().numpy()
+                for dom in doms[s]:
+                    exp = orc.quantize_matrix([x], [dom], [3, m])[orc.split_domain(dom, lens[s])[1]]
+                    np.testing.assert_array_equal(out[row].astype(np.int64), exp, err_msg=f'{tdtype} D={D} m={m} seq {s} {dom}')
+                    row += 1
+            assert row == out.shape[0]
+    finally:
+        ctx.set_option('path', 0)

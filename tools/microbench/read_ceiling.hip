@@ -138,6 +138,55 @@ __global__ __launch_bounds__(S * 64) void walk_fma_kernel(const float* __restric
     if (t == 12345.678) out[blockIdx.x] = t + lds[threadIdx.x];
 }
 
+// Half-precision rows in the walk shape: 4 channels per lane = 8 bytes, two 256-byte mirror segments per row and wave.
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+template <int S, int U, int K>
+__global__ __launch_bounds__(S * 64) void walk_half_kernel(const float* __restrict__ in, int rows, int jobs_per_wg, double* __restrict__ out,
+                                                           double c0, double c1) {
+    extern __shared__ double lds[];
+    typedef const v2f_ __attribute__((address_space(1))) * GP2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ld_f = (int64_t)S * 128;  // a row of S x 256 halves = S x 128 floats' worth of bytes
+    double acc[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[k][e] = 0.0;
+    for (int g = 0; g < jobs_per_wg; ++g) {
+        const int64_t job = (int64_t)blockIdx.x * jobs_per_wg + g;
+        const float* base = in + job * rows * ld_f + (lane < 32 ? wave * 64 + lane * 2 : S * 128 - 64 * (wave + 1) + (lane - 32) * 2);
+        for (int r = 0; r + U <= rows; r += U) {
+            v2f_ x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load((GP2)(uintptr_t)(base + (int64_t)(r + u) * ld_f));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double ca = c0 + (r + u) * c1, cb = c1 - (r + u) * c0;
+                const uint32_t w0 = __float_as_uint(x[u][0]), w1 = __float_as_uint(x[u][1]);
+                const _Float16 h[4] = {__builtin_bit_cast(_Float16, (unsigned short)(w0 & 0xffff)), __builtin_bit_cast(_Float16, (unsigned short)(w0 >> 16)),
+                                       __builtin_bit_cast(_Float16, (unsigned short)(w1 & 0xffff)), __builtin_bit_cast(_Float16, (unsigned short)(w1 >> 16))};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double v = (double)(float)h[e];
+#pragma unroll
+                    for (int k = 0; k < K / 2; ++k) {
+                        const double d = v - (double)(lane + k);
+                        acc[2 * k][e] = fma(d, ca, acc[2 * k][e]);
+                        acc[2 * k + 1][e] = fma(d, cb, acc[2 * k + 1][e]);
+                    }
+                }
+            }
+        }
+    }
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t += acc[k][e];
+    if (t == 12345.678) out[blockIdx.x] = t + lds[threadIdx.x];
+}
+
 #define CK(x)                                                                          \
     do {                                                                               \
         hipError_t e_ = (x);                                                           \
@@ -262,6 +311,23 @@ int main() {
             TIME(name, n_jobs* job_bytes,
                  hipLaunchKernelGGL((walk_fma_kernel<5, 8, 4, 1, 1>), dim3((unsigned)(n_jobs / 2)), dim3(320), lds_kb * 1024, 0, in, rows, 2,
                                     out, 0.5, 0.25));
+        }
+    }
+    // half-precision rows: 8 bytes per lane, walk shape (D = 1280 halves: S = 5), 496 rows
+    {
+        const int rows = 496;
+        const int64_t job_bytes = (int64_t)rows * 5 * 512;
+        const int64_t n_jobs = total_bytes / job_bytes / 2 * 2;
+        for (int lds_kb : {1, 48}) {
+            snprintf(name, sizeof name, "walk half S=5 L=496 K=2 plain U=8  (8 B per lane) lds %2d KB/wg", lds_kb);
+            TIME(name, n_jobs * job_bytes,
+                 hipLaunchKernelGGL((walk_half_kernel<5, 8, 2>), dim3((unsigned)(n_jobs / 2)), dim3(320), lds_kb * 1024, 0, in, rows, 2, out, 0.5, 0.25));
+            snprintf(name, sizeof name, "walk half S=5 L=496 K=2 plain U=16 (8 B per lane) lds %2d KB/wg", lds_kb);
+            TIME(name, n_jobs * job_bytes,
+                 hipLaunchKernelGGL((walk_half_kernel<5, 16, 2>), dim3((unsigned)(n_jobs / 2)), dim3(320), lds_kb * 1024, 0, in, rows, 2, out, 0.5, 0.25));
+            snprintf(name, sizeof name, "walk half S=5 L=496 K=4 fused U=8  (8 B per lane) lds %2d KB/wg", lds_kb);
+            TIME(name, n_jobs * job_bytes,
+                 hipLaunchKernelGGL((walk_half_kernel<5, 8, 4>), dim3((unsigned)(n_jobs / 2)), dim3(320), lds_kb * 1024, 0, in, rows, 2, out, 0.5, 0.25));
         }
     }
     return 0;
