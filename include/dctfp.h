@@ -188,12 +188,13 @@ int dctfp_stream_synchronize(void* stream);
 
 /* Tuning / instrumentation knobs (no reference counterpart).
  *   "path"         0 (default) = by shape: the walk kernel (stage A + stage B in one launch, nothing but int8 written)
- *                  for n = 3, 64 < m <= 80, float32 rows, 512 <= D <= 2560; stage A -> scratch -> stage B otherwise;
- *                  1 = always the two-kernel path; 2 = the walk kernel wherever its shapes allow (also D <= 2560)
+ *                  for n = 3, 64 < m <= 80, float32 / float16 / bfloat16 rows, 512 <= D <= 2560 and calls of 256 jobs
+ *                  (layers x domains) or more; stage A -> scratch -> stage B otherwise;
+ *                  1 = always the two-kernel path; 2 = the walk kernel wherever its shapes allow (any number of jobs)
  *   "last_path"    read only: which kernels the last dctfp_quantize launched (1 = two kernels, 2 = walk kernel)
  *   "ab_group"     walk kernel: jobs per stage-B flush (0 = auto = 4, 3, 4)
- *   "ab_unroll"    walk kernel: rows in flight per wave (0 = 8; 4, 6, 8)
- *   "ab_run_jobs"  walk kernel: jobs per workgroup (0 = by batch size)
+ *   "ab_unroll"    walk kernel: rows in flight per wave (0 = 8; 4, 6, 8; float32 rows only)
+ *   "ab_run_jobs"  walk kernel: jobs per workgroup (0 = by the bytes per job and the size of the call)
  *   "ab_longest_first" walk kernel: workgroups ordered by the rows they stream, longest first (0 = auto: batches of
  *                  domains at D > 1280, 1 = always, 2 = never)
  *   "small_b_jobs" two-kernel path: calls with fewer jobs (layers x domains) than this run stage B over 64-channel slabs
