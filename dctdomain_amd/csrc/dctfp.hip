@@ -993,7 +993,8 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         if (fuse && n == 3 && vec == 8) vec = 4;
 
         // ---- which kernels.  The walk kernel (stage A + B in one launch, nothing but int8 written) takes the
-        // production shapes: n = 3, 64 < m <= 80 (five 16-column groups), float32 rows read 16 B per lane, 512 <= D <= 2560, no giant domain
+        // production shapes: n = 3, 64 < m <= 80 (five 16-column groups), float32 / float16 / bfloat16 rows read 4 channels per lane,
+        // 512 <= D <= 2560, no giant domain
         // (a wave streams all rows of its channels).  Everything else runs stage A -> Y' -> stage B.
         const bool half_rows = g.dtype == DCTFP_F16 || g.dtype == DCTFP_BF16;  // (their `vec` is 8, or 4 for fused walks: the walk kernel reads 4)
         const bool walk_ok = !trivial && n == 3 && m > 64 && m <= 80 && ((g.dtype == DCTFP_F32 && vec == 4) || (half_rows && vec >= 4)) && g.n_cols >= 512 &&
@@ -1008,7 +1009,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         int walk_s = 0, walk_g = 0;
         if (use_walk) {
             walk_s = g.n_cols <= 768 ? 3 : (g.n_cols <= 1280 ? 5 : 10);
-            // jobs per flush: 4 leaves LDS for 17 waves per CU (S = 10: 3, so that two workgroups fit)
+            // jobs per flush: 4 = the rows of an MFMA tile (a flush costs the same MFMAs for 1..4 jobs)
             walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : 4;
             for (int64_t j = 0; j < n_jobs;) {
                 const int64_t d = j % n_domains;
