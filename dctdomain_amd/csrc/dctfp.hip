@@ -158,6 +158,7 @@ struct EventPair {
 }  // namespace
 
 constexpr int kMaxSlots = 8;
+constexpr size_t kCounterBytes = 16 * sizeof(unsigned long long);  // [0] degenerate channels; [1..11] phase cycles of an instrumented build; [15] device address of the host flag
 
 struct dctfp_ctx {
     int device = 0;
@@ -209,9 +210,13 @@ struct dctfp_ctx {
     std::unordered_map<uint64_t, double*> basis_tabs;
     size_t basis_doubles = 0;
     unsigned long long* degenerate = nullptr;  // device counter: exactly constant channels seen (see dctfp.h)
+    uint32_t* flag_host = nullptr;             // pinned + mapped word the kernels set when they see one (option degenerate_seen)
     int n_cu = 256;  // compute units of the device (workgroup slots of the walk kernel = n_cu x workgroups per CU)
     int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
+    int64_t test_fail_once = 0;                    // test hook: the next dctfp_quantize fails after its table lookups
+    int64_t basis_cap_doubles = (int64_t)1 << 27;  // 1 GiB of cosine tables, then the arena starts over (test hook: basis_cap_kb)
+    int64_t basis_restarts = 0;                    // how often it did
     std::map<std::pair<int, int>, StEntry> st_cache;
     uint64_t tick = 0;
     std::vector<EventPair> events;
@@ -344,7 +349,6 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
 }
 
 constexpr size_t kBasisSlabDoubles = (size_t)1 << 20;   // 8 MB pieces
-constexpr size_t kBasisCapDoubles = (size_t)1 << 27;    // 1 GiB of tables, then the arena starts over
 
 // Drops every cosine table (only between calls: nothing may be in flight).
 int basis_purge(dctfp_ctx* ctx) {
@@ -354,11 +358,14 @@ int basis_purge(dctfp_ctx* ctx) {
     ctx->basis_tabs.clear();
     ctx->basis_doubles = 0;
     ctx->basis_valid = false;
+    ctx->basis_restarts += 1;
     return DCTFP_OK;
 }
 
-// Device address of the cosine table of (len, nk); a table seen for the first time is appended to `fresh`
-// (the caller launches basis_kernel for those before anything reads them).
+// Device address of the cosine table of (len, nk); a table seen for the first time gets its room in the arena and is
+// appended to `fresh`.  It is NOT in the cache yet: the caller launches basis_kernel for the fresh tables and only then
+// publishes them (basis_publish); every error exit in between gives the room back (BasisRollback) -- a length cached
+// before its table is filled would hand uninitialised cosines to every later call.
 int basis_lookup(dctfp_ctx* ctx, uint32_t len, int nk, double** out, std::vector<BasisJob>& fresh) {
     const uint64_t key = ((uint64_t)nk << 32) | len;
     auto it = ctx->basis_tabs.find(key);
@@ -378,7 +385,6 @@ int basis_lookup(dctfp_ctx* ctx, uint32_t len, int nk, double** out, std::vector
     double* tab = sl.dev + sl.used;
     sl.used += need;
     ctx->basis_doubles += need;
-    ctx->basis_tabs.emplace(key, tab);
     BasisJob bj;
     bj.tab = tab;
     bj.len = len;
@@ -387,6 +393,34 @@ int basis_lookup(dctfp_ctx* ctx, uint32_t len, int nk, double** out, std::vector
     *out = tab;
     return DCTFP_OK;
 }
+
+void basis_publish(dctfp_ctx* ctx, const std::vector<BasisJob>& fresh, int nk) {
+    for (const BasisJob& bj : fresh) ctx->basis_tabs.emplace(((uint64_t)nk << 32) | bj.len, bj.tab);
+}
+
+// State of the arena before a call reserves room for fresh tables; restore() undoes the reservations.
+struct BasisRollback {
+    dctfp_ctx* ctx;
+    size_t n_slabs, used_last, doubles;
+    bool armed = true;
+    explicit BasisRollback(dctfp_ctx* c)
+        : ctx(c), n_slabs(c->basis_slabs.size()), used_last(c->basis_slabs.empty() ? 0 : c->basis_slabs.back().used),
+          doubles(c->basis_doubles) {}
+    void restore() {
+        if (ctx->basis_slabs.size() > n_slabs) {
+            (void)hipDeviceSynchronize();
+            while (ctx->basis_slabs.size() > n_slabs) {
+                (void)hipFree(ctx->basis_slabs.back().dev);
+                ctx->basis_slabs.pop_back();
+            }
+        }
+        if (n_slabs > 0) ctx->basis_slabs[n_slabs - 1].used = used_last;
+        ctx->basis_doubles = doubles;
+    }
+    ~BasisRollback() {
+        if (armed) restore();
+    }
+};
 
 template <int N>
 InvTab<N> make_inv() {
@@ -544,6 +578,10 @@ template <int S, int G>
 int launch_walk_u(const WParams& p, int unroll, bool fused) {
     if (unroll == 4) launch_walk_impl<float, S, G, 5, 4>(p, fused);
     else if (unroll == 6) launch_walk_impl<float, S, G, 5, 6>(p, fused);
+#ifdef DCTFP_EXPERIMENTS
+    else if (unroll == 12 && S == 10) launch_walk_impl<float, 10, G, 5, 12>(p, fused);
+    else if (unroll == 16 && S == 10) launch_walk_impl<float, 10, G, 5, 16>(p, fused);
+#endif
     else launch_walk_impl<float, S, G, 5, 8>(p, fused);
     return DCTFP_OK;
 }
@@ -616,9 +654,19 @@ int dctfp_create(int device, dctfp_ctx** out) {
     if (!ctx) return fail(DCTFP_ERR_NOMEM, "dctfp_create: out of host memory");
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    hipError_t e = hipMalloc((void**)&ctx->degenerate, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ctx->degenerate, 0, sizeof(unsigned long long));
+    hipError_t e = hipMalloc((void**)&ctx->degenerate, kCounterBytes);
+    if (e == hipSuccess) e = hipMemset(ctx->degenerate, 0, kCounterBytes);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->flag_host, 64, hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *ctx->flag_host = 0;
+        void* flag_dev = nullptr;
+        e = hipHostGetDevicePointer(&flag_dev, ctx->flag_host, 0);
+        const unsigned long long addr = (unsigned long long)(uintptr_t)flag_dev;
+        if (e == hipSuccess) e = hipMemcpy(ctx->degenerate + kFlagSlot, &addr, sizeof addr, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
+        if (ctx->degenerate) (void)hipFree(ctx->degenerate);
+        if (ctx->flag_host) (void)hipHostFree(ctx->flag_host);
         delete ctx;
         return fail(DCTFP_ERR_HIP, "dctfp_create: %s", hipGetErrorString(e));
     }
@@ -641,6 +689,7 @@ int dctfp_destroy(dctfp_ctx* ctx) {
     }
     for (auto& sl : ctx->basis_slabs) (void)hipFree(sl.dev);
     if (ctx->degenerate) (void)hipFree(ctx->degenerate);
+    if (ctx->flag_host) (void)hipHostFree(ctx->flag_host);
     for (auto& e : ctx->events) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -689,6 +738,9 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         if (value != 0 && value != 3 && value != 4) return fail(DCTFP_ERR_INVALID, "ab_group must be 0 (auto), 3 or 4 jobs per flush");
         ctx->opt_ab_group = value;
     } else if (n == "ab_unroll") {
+#ifdef DCTFP_EXPERIMENTS
+        if (value == 12 || value == 16) { ctx->opt_ab_unroll = value; return DCTFP_OK; }
+#endif
         if (value != 0 && value != 4 && value != 6 && value != 8) return fail(DCTFP_ERR_INVALID, "ab_unroll must be 0 (auto), 4, 6 or 8");
         ctx->opt_ab_unroll = value;
     } else if (n == "small_b_jobs") {
@@ -704,7 +756,13 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         if (value != 0) return fail(DCTFP_ERR_INVALID, "degenerate_channels can only be reset to 0");
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemset(ctx->degenerate, 0, sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(ctx->degenerate, 0, kFlagSlot * sizeof(unsigned long long)));  // (slot 15 keeps the flag's address)
+        *ctx->flag_host = 0;
+    } else if (n == "test_fail_once") {
+        ctx->test_fail_once = value ? 1 : 0;
+    } else if (n == "basis_cap_kb") {
+        if (value < 1) return fail(DCTFP_ERR_INVALID, "basis_cap_kb must be >= 1");
+        ctx->basis_cap_doubles = value * 128;
     } else if (n == "overlap") {
         if (value < 1 || value > kMaxSlots) return fail(DCTFP_ERR_INVALID, "overlap must be 1..%d", kMaxSlots);
         ctx->opt_overlap = value;
@@ -741,7 +799,25 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
         HIP_TRY(hipMemcpy(&v, ctx->degenerate, sizeof v, hipMemcpyDeviceToHost));
         *value = (int64_t)v;
     }
+#ifdef DCTFP_WALK_TIMELINE
+    else if (n.rfind("walk_timeline_", 0) == 0) {  // instrumented build: cycles per phase (kernels.hip.h), synchronises the device
+        const int i = atoi(n.c_str() + 14);
+        if (i < 0 || i > 10) return fail(DCTFP_ERR_INVALID, "walk_timeline_0 .. walk_timeline_10");
+        unsigned long long v = 0;
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(&v, ctx->degenerate + 1 + i, sizeof v, hipMemcpyDeviceToHost));
+        *value = (int64_t)v;
+    }
+#endif
+    else if (n == "degenerate_seen") {  // no device synchronisation: meaningful once the caller has waited for its call
+        *value = *(volatile uint32_t*)ctx->flag_host ? 1 : 0;
+        *(volatile uint32_t*)ctx->flag_host = 0;
+    }
     else if (n == "fuse") *value = ctx->opt_fuse;
+    else if (n == "basis_cap_kb") *value = ctx->basis_cap_doubles / 128;
+    else if (n == "basis_restarts") *value = ctx->basis_restarts;
+    else if (n == "basis_tables") *value = (int64_t)ctx->basis_tabs.size();
     else if (n == "pack_y") *value = ctx->opt_pack_y;
     else if (n == "profile") *value = ctx->opt_profile;
     else if (n == "workspace_mb") *value = ctx->opt_ws_mb;
@@ -889,7 +965,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
     }
 
     // ---- groups of consecutive layers with the same geometry ----------------------
-    if (ctx->basis_doubles > kBasisCapDoubles) {  // the cosine-table arena starts over (nothing of this call uses it yet)
+    if ((int64_t)ctx->basis_doubles > ctx->basis_cap_doubles) {  // the cosine-table arena starts over (nothing of this call uses it yet)
         int rcp = basis_purge(ctx);
         if (rcp) return rcp;
     }
@@ -929,6 +1005,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         BasisJob* hbt = (BasisJob*)(h + off_btab);
 
         // one cosine table per distinct domain length, from the context's cache
+        BasisRollback basis_guard(ctx);  // until the fresh tables are filled and published
         std::vector<BasisJob> fresh;
         std::vector<double*> dom_tab((size_t)n_domains, nullptr);
         if (!trivial) {
@@ -1224,7 +1301,14 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         if (rc) return rc;
         const int ldy = st->ldy;
 
+        if (ctx->test_fail_once) {  // test hook: an allocation failure between the table lookup and the fill kernel
+            ctx->test_fail_once = 0;
+            return fail(DCTFP_ERR_NOMEM, "injected failure (option test_fail_once)");
+        }
         if (!fresh.empty()) {  // cosine tables this context has not seen yet (grid.y is limited to 65535)
+            // tables cached by earlier calls may have been filled on another stream: chain the events, so that whoever
+            // waits for the new ev_basis also has the older fills behind it
+            if (ctx->basis_valid && ctx->basis_stream != ts) HIP_TRY(hipStreamWaitEvent(ts, ctx->ev_basis, 0));
             uint32_t max_len = 0;
             for (const BasisJob& bj : fresh) max_len = std::max(max_len, bj.len);
             const unsigned gx = (unsigned)std::min<uint64_t>(((2 * (uint64_t)max_len + 1) * nk + 255) / 256, 1024);
@@ -1238,7 +1322,9 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             HIP_TRY(hipEventRecord(ctx->ev_basis, ts));
             ctx->basis_stream = ts;
             ctx->basis_valid = true;
+            basis_publish(ctx, fresh, nk);
         }
+        basis_guard.armed = false;
         if (!inline_tables) {
             HIP_TRY(hipEventRecord(ctx->ev_tab_ready, ctx->copy));
             HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_ready, 0));

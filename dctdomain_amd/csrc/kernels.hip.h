@@ -190,6 +190,16 @@ __device__ inline void store_through(V* p, V v) {
 // the reference at the other lengths (tests/golden/fence_golden.json) -- the one input class where the
 // result is reported instead of matched.
 // ---------------------------------------------------------------------------
+// counters[0] += 1, and a plain store of 1 into the context's host-mapped flag word (its device address sits in
+// counters[kFlagSlot]): the host learns "this call saw one" from its own memory after the stream synchronisation it
+// does anyway -- no copy, no extra wait (Fingerprint.quantize / make_db log a warning with the protein's id).
+constexpr int kFlagSlot = 15;
+__device__ __noinline__ void note_degenerate(unsigned long long* __restrict__ counters) {
+    atomicAdd(counters, 1ull);
+    volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>((uintptr_t)counters[kFlagSlot]);
+    if (flag) *flag = 1u;
+}
+
 template <int N>
 __device__ inline void scale_channel(const double (&f)[N > 1 ? N - 1 : 1], const InvTab<N>& inv, bool pad, double (&z)[N],
                                      unsigned long long* __restrict__ degenerate) {
@@ -208,7 +218,7 @@ __device__ inline void scale_channel(const double (&f)[N > 1 ? N - 1 : 1], const
         mx = fmax(mx, s);
     }
     const double den = mx - mn;
-    if (!bad && den == 0.0 && !pad) atomicAdd(degenerate, 1ull);
+    if (!bad && den == 0.0 && !pad) note_degenerate(degenerate);
 #pragma unroll
     for (int j = 0; j < N; ++j) z[j] = pad ? 0.0 : (bad ? __builtin_nan("") : (y[j] - mn) / den);
 }
@@ -244,7 +254,7 @@ __device__ inline void scale_pack3(const double (&f)[2], const InvTab<3>& inv, b
         mx = fmax(mx, s);
     }
     const double den = mx - mn;
-    if (!bad && den == 0.0 && !pad) atomicAdd(degenerate, 1ull);
+    if (!bad && den == 0.0 && !pad) note_degenerate(degenerate);
     const bool zero_ok = den > 0.0;                    // 0 / den = 0   (else 0 / 0 or 0 / NaN = NaN)
     const bool one_ok = zero_ok && den < INFINITY;     // den / den = 1 (else inf / inf = NaN)
     const bool den_inf = den == INFINITY;              // finite / inf = 0
@@ -936,6 +946,30 @@ constexpr int kWalkChannels = 256;  // channels per wave: 64 lanes x 4 float32
 #define DCTFP_WALK_B_DEPTH 1         // k-steps of stage-B fragments in flight during a flush (1, 2, 4); more was never faster:
 #endif                               // what a flush costs is issue time, not L2 latency (profiles/r02/experiments/flush_*)
 
+// Instrumented build (tools/walk_timeline.py; never the shipped library): every wave adds the shader-clock cycles it
+// spends per phase to degenerate[1 + phase] -- 0 stream (job record -> last row accumulated), 1 epilogue, 2 flush
+// contraction (unpack + MFMA), 3 wait at the barrier before the cross-wave sum, 4 cross-wave sum + int8, 5 wait at the
+// barrier that frees the slots, 6 everything else, 7 wave lifetime; 8 waves, 9 jobs, 10 flushes.
+#ifdef DCTFP_WALK_TIMELINE
+#define DCTFP_TL_DECL                                   \
+    uint64_t tl_prev = __builtin_amdgcn_s_memtime();    \
+    const uint64_t tl_begin = tl_prev;                  \
+    uint64_t tl_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define DCTFP_TL_MARK(i)                                         \
+    do {                                                         \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime();      \
+        tl_acc[i] += now_ - tl_prev;                             \
+        tl_prev = now_;                                          \
+    } while (0)
+#define DCTFP_TL_COUNT(i) tl_acc[i] += 1
+#define DCTFP_TL_ANCHOR(x) asm volatile("" ::"v"(x))
+#else
+#define DCTFP_TL_DECL
+#define DCTFP_TL_MARK(i)
+#define DCTFP_TL_COUNT(i)
+#define DCTFP_TL_ANCHOR(x)
+#endif
+
 template <typename T, int S, int G, int NT, int UNROLL, bool FUSED>
 __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
                                                           const Walk* __restrict__ walks, const Run* __restrict__ runs,
@@ -968,6 +1002,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
 
     uint32_t pending = 0;            // jobs whose Y' sits in LDS
     uint32_t group_job = run.job_begin;  // job of slot 0
+    DCTFP_TL_DECL
 
     for (uint32_t wi = 0; wi < run.n_walks; ++wi) {
         const Walk wk = walks[run.walk_begin + wi];
@@ -983,6 +1018,8 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
 
         for (uint32_t part = 0; part < n_walk_jobs; ++part) {
             double f[NK][VEC];
+            DCTFP_TL_MARK(6);
+            DCTFP_TL_COUNT(9);
             if (part < wk.n_parts) {
                 // ---- stage A of one job: every row of this wave's 256 channels
                 const JobA job = jobs[wk.job_begin + part];
@@ -1035,8 +1072,9 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
 #pragma unroll
                         for (int u = 0; u < UNROLL; ++u) row_update(xv[u], r + u);
                     }
-                    if constexpr (UNROLL > 4) {  // what is left of the piece: a group of 4 ...
-                        if (r + 4 <= piece.n_rows) {
+                    if constexpr (UNROLL > 4) {  // what is left of the piece: groups of 4 (one at most up to 8 rows in flight) ...
+                        for (int g4 = 0; g4 < (UNROLL - 1) / 4; ++g4) {
+                            if (r + 4 > piece.n_rows) break;
                             Rw xv[4];
 #pragma unroll
                             for (int u = 0; u < 4; ++u) xv[u] = load_raw<T, VEC>(base + (size_t)(r + u) * ld);
@@ -1082,6 +1120,9 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
             }
 
             // ---- epilogue of the job: scale each of my 4 channels, pack into my slot (wave-private, no barrier)
+            DCTFP_TL_ANCHOR(f[0][0]);
+            DCTFP_TL_ANCHOR(f[1][VEC - 1]);
+            DCTFP_TL_MARK(0);
             {
                 v4d t4;
                 uint32_t c4 = 0;
@@ -1099,8 +1140,10 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 lds_c[wave][pending][lane] = c4;
             }
             ++pending;
+            DCTFP_TL_MARK(1);
             const bool last = (wi + 1 == run.n_walks) && (part + 1 == n_walk_jobs);
             if (pending < (uint32_t)G && !last) continue;
+            DCTFP_TL_COUNT(10);
 
             // ---- flush: stage B of the `pending` jobs in LDS
             // Both cosine factors of St[d][c] = sum_k cos_m(k, c) cos_D(k, d) are mirror (anti)symmetric:
@@ -1180,7 +1223,9 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                         for (int c = 0; c < NT; ++c) lds_t[wave][lane >> 4][jr * (NT * 16) + c * 16 + (lane & 15)] = acc[jr][c];
                 }
             }
+            DCTFP_TL_MARK(2);
             __syncthreads();
+            DCTFP_TL_MARK(3);
             // sum over the waves in wave order, Z[c] = ZE[c] + ZO[c] and Z[m-1-c] = ZE[c] - ZO[c], per-row min-max scale, int8
             // (src/fingerprint.py:193-195); lane c < ceil(m / 2) holds both
             const int hm = (m + 1) >> 1;
@@ -1220,11 +1265,22 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 if (valid[0]) o[lane] = quant127(v[0] - mn, den, bad != 0);
                 if (valid[1]) o[m - 1 - lane] = quant127(v[1] - mn, den, bad != 0);
             }
+            DCTFP_TL_MARK(4);
             __syncthreads();  // the slots are free again
+            DCTFP_TL_MARK(5);
             group_job += pending;
             pending = 0;
         }
     }
+#ifdef DCTFP_WALK_TIMELINE
+    DCTFP_TL_MARK(6);
+    tl_acc[7] = tl_prev - tl_begin;
+    tl_acc[8] = 1;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) atomicAdd(degenerate + 1 + i, (unsigned long long)tl_acc[i]);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------

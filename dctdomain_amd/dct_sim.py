@@ -68,6 +68,18 @@ def load_dct(filename: str, asmap=True) -> tuple:
     return (dict(zip(seqid, per_protein)) if asmap else per_protein), seqid
 
 
+def _protein_groups(idx, max_rows: int):
+    """[p0, p1) ranges of consecutive proteins whose fingerprints (idx = prefix offsets) number at most ``max_rows``
+    -- at least one protein per range, however many fingerprints it has."""
+    p0, n = 0, len(idx) - 1
+    while p0 < n:
+        p1 = p0 + 1
+        while p1 < n and idx[p1 + 1] - idx[p0] <= max_rows:
+            p1 += 1
+        yield p0, p1
+        p0 = p1
+
+
 class Blocks:
     """All protein-vs-protein (minimum, last-last) L1 blocks between two ``-dct.npz`` files."""
 
@@ -80,21 +92,25 @@ class Blocks:
         self.rows, self.cols = a['sid'], b['sid']
         # protein stripes of `a`: the int32 distance matrix of a stripe stays within ~1 GiB (the protein x protein result
         # is what is kept; the reference loops pair by pair, src/dct-sim.py:126-176)
+        # ... and protein groups of `b` of at most COL_ROWS fingerprints, so that neither the uploaded part of `b` nor
+        # the distance matrix grows with the size of the files
         da, ia = a['dct'], np.asarray(a['idx'], dtype=np.int64)
-        db_dev = to_device_int8(b['dct'])
-        budget = max(1, (1 << 28) // max(1, db_dev.shape[0]))
-        mns, lasts, p0 = [], [], 0
-        while p0 < len(ia) - 1:
-            p1 = p0 + 1
-            while p1 < len(ia) - 1 and ia[p1 + 1] - ia[p0] <= budget:
-                p1 += 1
-            mn_t, last_t = block_min(l1_matrix(da[ia[p0]:ia[p1]], db_dev), ia[p0:p1 + 1] - ia[p0], b['idx'])
-            mns.append(mn_t)
-            lasts.append(last_t)
-            p0 = p1
-        nb = len(b['idx']) - 1
-        self.mn = np.concatenate(mns) if mns else np.zeros((0, nb), np.int32)
-        self.last = np.concatenate(lasts) if lasts else np.zeros((0, nb), np.int32)
+        dbm, ib = b['dct'], np.asarray(b['idx'], dtype=np.int64)
+        na, nb = len(ia) - 1, len(ib) - 1
+        self.mn = np.full((na, nb), 0x7fffffff, dtype=np.int32)      # (an empty block keeps this: block_min_kernel's fill)
+        self.last = np.full((na, nb), 0x7fffffff, dtype=np.int32)
+        for q0, q1 in _protein_groups(ib, self.COL_ROWS):
+            db_dev = to_device_int8(dbm[ib[q0]:ib[q1]])
+            budget = max(1, self.TILE_INTS // max(1, db_dev.shape[0]))
+            for p0, p1 in _protein_groups(ia, budget):
+                if ia[p1] > ia[p0] and db_dev.shape[0] > 0:           # (a stripe of proteins without fingerprints: nothing to launch)
+                    mn_t, last_t = block_min(l1_matrix(da[ia[p0]:ia[p1]], db_dev), ia[p0:p1 + 1] - ia[p0], ib[q0:q1 + 1] - ib[q0])
+                    self.mn[p0:p1, q0:q1] = mn_t
+                    self.last[p0:p1, q0:q1] = last_t
+            del db_dev
+
+    COL_ROWS = 1 << 22      # fingerprints of `b` on the device at a time (2 GB of int8 at 480 columns)
+    TILE_INTS = 1 << 28     # int32 entries of one distance matrix (1 GiB)
 
     def scores(self, i: int, j: int) -> tuple:
         return _scores(self.mn[i, j], self.last[i, j])

@@ -17,6 +17,7 @@ CPU implementation behind this class: without libdctfp.so and a GPU it raises.
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import threading
 from dataclasses import dataclass, field
 
@@ -26,6 +27,19 @@ import torch
 from . import _lib
 from .batch import PieceTable, host_pointer
 from .domains import split_domain
+
+
+CONSTANT_CHANNEL_NOTE = (
+    'an embedding channel is exactly constant over a domain: its min-max scale is 0/0, so the (layer, domain) block of '
+    'the fingerprint is all 0.  The reference (scipy/pocketfft) gives the same block at most domain lengths but scales '
+    'its own round-off noise at 225 of the lengths 3..2000 (tests/golden/fence_golden.json, INTEGRATION.md section 5): '
+    'for these blocks the result is reported, not matched')
+
+
+def warn_constant_channel(pids):
+    """The one documented deviation from the reference must not be silent in the drop-in: a warning naming the proteins
+    (``make_db --out`` puts it into the log file)."""
+    logging.warning(f"constant channel in {', '.join(str(p) for p in pids)}: {CONSTANT_CHANNEL_NOTE}")
 
 
 def _device():
@@ -205,6 +219,9 @@ class Fingerprint:
                 groups.append((table, (buf, off), width, i, j))
             i = j + 1
         hosts = _fetch_results(groups, stream)
+        if groups and _lib.get_context(dev.index if dev.index is not None else torch.cuda.current_device()) \
+                .get_option('degenerate_seen'):
+            warn_constant_channel([self.pid])
 
         # quants[key] = the blocks of every layer, layer-major, then domain order (:184-196); a key that occurs
         # twice (two domain strings cleaned to the same key) is extended twice, as there

@@ -47,7 +47,8 @@ def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, thres
     it one by one, with three batched steps instead of a process pool (src/make_db.py:36-51)."""
     from . import reccut
     from .batch import LayerBatch, PieceTable, quantize_batch
-    from .fingerprint import _to_device_matrix
+    from . import _lib
+    from .fingerprint import _to_device_matrix, warn_constant_channel
     if not fps:
         return fps
     lens = [len(fp.seq) for fp in fps]
@@ -65,6 +66,9 @@ def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, thres
     layers = [LayerBatch(mats[i], qdim[2 * i], qdim[2 * i + 1]) for i in range(len(keys0))]
     out = quantize_batch(layers, table)
     host = out.cpu().numpy().astype(np.int64) if table.n_domains else np.zeros((0, 0), np.int64)
+    if table.n_domains and _lib.get_context(out.device.index).get_option('degenerate_seen'):
+        # rare: the flush saw an exactly constant channel (0/0 -> all-zero block, the documented deviation).  Name the proteins.
+        warn_constant_channel(_constant_channel_pids(fps, mats, table) or [fp.pid for fp in fps])
     blocks, off = [], 0
     for i in range(len(keys0)):
         nm = qdim[2 * i] * qdim[2 * i + 1]
@@ -85,6 +89,27 @@ def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, thres
         fp.domains = list(fp.quants.keys())
         logging.info(f'{datetime.datetime.now()} Fingerprinted {fp.pid}')
     return fps
+
+
+def _constant_channel_pids(fps, mats, table):
+    """Proteins of a flush with a domain in which some channel of some layer is exactly constant (only run after the
+    kernels flagged one; a handful of torch reductions per domain)."""
+    hit = []
+    pieces = table.pieces
+    first = 0
+    for d in range(table.n_domains):
+        last = first
+        while last < len(pieces) and pieces['domain'][last] == d:
+            last += 1
+        s = table.owner[d]
+        if not hit or hit[-1] != fps[s].pid:
+            for layer in mats:
+                rows = torch.cat([layer[s][int(p['row_start']):int(p['row_start']) + int(p['n_rows'])] for p in pieces[first:last]])
+                if bool((rows.max(dim=0).values == rows.min(dim=0).values).any()):
+                    hit.append(fps[s].pid)
+                    break
+        first = last
+    return hit
 
 
 def load_model(name: str, device):
@@ -199,12 +224,18 @@ def _run_workers(n_gpu: int, worker_args: tuple, sink, target=None, poll_s: floa
             for p in procs:
                 if p.is_alive():
                     p.terminate()
+        # a worker that has said 'done' may still be tearing down its model / HIP context: wait for it (exitcode None =
+        # still running, not a failure); one that is stuck in teardown after delivering everything is ended, not raised
         for p in procs:
-            p.join(timeout=30)
+            p.join(timeout=30 if failure is not None else 600)
     if failure is not None:
         raise RuntimeError(failure)
     for r, p in enumerate(procs):
-        if p.exitcode != 0:
+        if p.exitcode is None:
+            logging.warning(f'GPU worker {r} delivered its shard but did not exit within 600 s; terminating it')
+            p.terminate()
+            p.join(timeout=30)
+        elif p.exitcode != 0:
             raise RuntimeError(f'GPU worker {r} exited with code {p.exitcode}')
 
 
@@ -218,6 +249,8 @@ class OrderedWriter:
     def __init__(self, db: Database, pending):
         self.db = db
         self.order = {pid: i for i, (pid, _) in enumerate(pending)}
+        if len(self.order) != len(pending):       # (pid is the PRIMARY KEY of `sequences`: cannot happen from a database)
+            raise ValueError('duplicate protein ids in the pending list: the ordered writer would stall at the first one')
         self.next = 0                 # pending index of the next protein to write
         self.held = {}                # pending index -> record that arrived early
         self.written = 0

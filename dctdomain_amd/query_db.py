@@ -29,6 +29,10 @@ def _load_all(db: Database):
     return meta, np.array(blobs, dtype=np.int8)
 
 
+COL_ROWS = 1 << 22      # database fingerprints on the device at a time (2 GB of int8 at 480 columns)
+TILE_INTS = 1 << 28     # int32 entries of one distance matrix (1 GiB)
+
+
 def search(query_rows, query_fps, db_rows, db_fps, khits: int):
     """Yields the reference's log lines.  Per query protein (pids in the order ``SELECT pid FROM
     sequences`` returns them: by primary key, i.e. sorted): the ``khits`` nearest database
@@ -36,18 +40,34 @@ def search(query_rows, query_fps, db_rows, db_fps, khits: int):
     all of those ranked by distance (stable) and the first ``khits`` printed (:33-59)."""
     # query fingerprints in tiles: the (tile, ndb) int32 distance matrix stays within ~1 GiB however large the database
     # is (the reference streams one query protein at a time, src/query_db.py:75-87)
-    k = min(khits, db_fps.shape[0])
-    db_dev = to_device_int8(db_fps)
-    tile = max(64, min(8192, (1 << 28) // max(1, db_fps.shape[0])))
-    dms, ims = [], []
-    for q0 in range(0, len(query_fps), tile):
-        dist = l1_matrix(query_fps[q0:q0 + tile], db_dev)                # (tile, ndb) int32 on the GPU
-        dm_t, im_t = row_select(dist, k)                                  # k nearest per query fingerprint
-        dms.append(dm_t)
-        ims.append(im_t)
-        del dist
-    dm = np.concatenate(dms) if dms else np.zeros((0, k), np.int64)
-    im = np.concatenate(ims) if ims else np.zeros((0, k), np.int64)
+    # ... and the database in column blocks of at most COL_ROWS fingerprints (uploaded one at a time): the k nearest of
+    # every block are candidates, the k nearest of the candidates the answer (ties: lower database row first, as before)
+    ndb = db_fps.shape[0]
+    k = min(khits, ndb)
+    nq = len(query_fps)
+    cand_d, cand_i = [], []                                 # per column block: (nq, k_block) distances / database rows
+    for c0 in range(0, ndb, COL_ROWS):
+        db_dev = to_device_int8(db_fps[c0:c0 + COL_ROWS])
+        kb = min(k, db_dev.shape[0])
+        tile = max(1, min(8192, TILE_INTS // max(1, db_dev.shape[0])))
+        dms, ims = [], []
+        for q0 in range(0, nq, tile):
+            dist = l1_matrix(query_fps[q0:q0 + tile], db_dev)            # (tile, block) int32 on the GPU
+            dm_t, im_t = row_select(dist, kb)                             # k nearest per query fingerprint
+            dms.append(dm_t)
+            ims.append(im_t + c0)
+            del dist
+        cand_d.append(np.concatenate(dms) if dms else np.zeros((0, kb), np.int64))
+        cand_i.append(np.concatenate(ims) if ims else np.zeros((0, kb), np.int64))
+        del db_dev
+    if len(cand_d) == 1:
+        dm, im = cand_d[0], cand_i[0]
+    elif cand_d:
+        v, i = np.concatenate(cand_d, axis=1), np.concatenate(cand_i, axis=1)
+        order = np.lexsort((i, v), axis=1)[:, :k]
+        dm, im = np.take_along_axis(v, order, axis=1), np.take_along_axis(i, order, axis=1)
+    else:
+        dm, im = np.zeros((nq, 0), np.int64), np.zeros((nq, 0), np.int64)
     by_pid = {}
     for qi, r in enumerate(query_rows):
         by_pid.setdefault(r[1], []).append(qi)

@@ -49,6 +49,9 @@ def block_min(dist: torch.Tensor, idx_a, idx_b):
     ia = torch.as_tensor(np.asarray(idx_a, dtype=np.int64), device=dist.device)
     ib = torch.as_tensor(np.asarray(idx_b, dtype=np.int64), device=dist.device)
     npa, npb = len(ia) - 1, len(ib) - 1
+    if dist.numel() == 0:       # proteins without a single fingerprint on either side: every block is empty
+        empty = np.full((npa, npb), 0x7fffffff, dtype=np.int32)     # what block_min_kernel writes for an empty block
+        return empty, empty.copy()
     mn = torch.empty((npa, npb), dtype=torch.int32, device=dist.device)
     last = torch.empty((npa, npb), dtype=torch.int32, device=dist.device)
     if mn.numel():

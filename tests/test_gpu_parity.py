@@ -55,11 +55,21 @@ def test_golden_errors(dd, case):
 SUBSET = [c for c in ALL_OK if c['id'].startswith(('two_', 'dom_', 'qdim_', 'contact', 'inline', 'deg_', 'c4_'))]
 
 
+def walk_eligible(case, layers):
+    """The shapes dctfp_quantize hands to walk_ab_kernel when path = 2 (dctfp.hip, "which kernels"): n = 3, 64 < m <= 80,
+    float32 rows read 4 channels per lane, 512 <= D <= 2560, no domain above 8192 rows -- judged on the LAST layer group,
+    the one `last_path` reports."""
+    x, n, m = layers[-1], case['qdim'][-2], case['qdim'][-1]
+    return n == 3 and 64 < m <= 80 and x.dtype == np.float32 and 512 <= x.shape[1] <= 2560 and x.shape[1] % 4 == 0 \
+        and x.shape[0] <= 8192 and len(case['keys']) > 0
+
+
 @pytest.mark.parametrize('opts', [dict(stage_b=0), dict(stage_b=1), dict(a_waves=8, a_unroll=4),
                                   dict(a_waves=16, a_unroll=8), dict(a_waves=4, a_unroll=4),
                                   dict(workspace_mb=16), dict(a_waves=2, a_unroll=8), dict(a_waves=1), dict(overlap=1), dict(fuse=0), dict(pack_y=0),
-                                  dict(path=1), dict(path=1, fuse=0), dict(ab_unroll=4), dict(ab_unroll=6), dict(ab_unroll=8), dict(ab_group=3), dict(ab_group=4), dict(path=2), dict(ab_run_jobs=4), dict(ab_run_jobs=64),
-                                  dict(ab_run_jobs=1), dict(small_b_jobs=0), dict(path=1, small_b_jobs=1 << 20)],
+                                  dict(path=1), dict(path=1, fuse=0), dict(path=2, ab_unroll=4), dict(path=2, ab_unroll=6), dict(path=2, ab_unroll=8),
+                                  dict(path=2, ab_group=3), dict(path=2, ab_group=4), dict(path=2), dict(path=2, ab_run_jobs=4), dict(path=2, ab_run_jobs=64),
+                                  dict(path=2, ab_run_jobs=1), dict(small_b_jobs=0), dict(path=1, small_b_jobs=1 << 20)],
                          ids=['valuB', 'mfmaB', 'w8u4', 'w16u8', 'w4u4', 'smallws', 'w2u8', 'w1', 'nooverlap', 'nofuse', 'nopack',
                               'twokernels', 'twokernels_nofuse', 'walk_u4', 'walk_u6', 'walk_u8', 'walk_g3', 'walk_g4', 'walk_forced', 'walk_run4', 'walk_run64', 'walk_run1', 'mfmaB_small_calls', 'slabB_always'])
 def test_kernel_variants_agree_with_golden(dd, opts):
@@ -72,6 +82,9 @@ def test_kernel_variants_agree_with_golden(dd, opts):
         for case in SUBSET:
             layers = gu.build_layers(case)
             fp = run_fp(dd, layers, case['domains'], case['qdim'], as_tensor=True)
+            if opts.get('path') == 2 and walk_eligible(case, layers):
+                # a one-protein call reaches the walk kernel only when it is forced: make sure it did
+                assert ctx.get_option('last_path') == 2, f"{case['id']} did not run walk_ab_kernel under {opts}"
             exp = gu.expected(case)
             assert list(fp.quants.keys()) == case['keys']
             for k in exp:

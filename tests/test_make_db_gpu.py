@@ -160,3 +160,65 @@ def test_config5_scale_build_two_workers_against_one_and_oracle(tmp_path):
             np.testing.assert_array_equal(za['dct'][za['idx'][k] + r].astype(np.int64), q[key], err_msg=f'{pid} {key}')
         n_multi += len(doms) > 1
     assert n_multi >= 5
+
+
+def test_constant_channel_is_reported_by_the_drop_in(tmp_path, monkeypatch):
+    """the one documented deviation from the reference -- an exactly constant channel gives 0/0 -> the
+    all-zero (layer, domain) block at EVERY domain length, where scipy's pocketfft scales round-off noise at 225 of the
+    lengths 3..2000 (tests/golden/fence_golden.json) -- must not be silent for a user of the drop-in: make_db logs a
+    warning naming the proteins (into --out), Fingerprint.quantize does the same for its one protein."""
+    import json
+    import logging
+    import dctdomain_amd as dd
+    from dctdomain_amd import make_db
+    from dctdomain_amd.embedding import SyntheticModel
+    noisy_lengths = set(json.load(open(os.path.join(gu.GOLD, 'fence_golden.json')))['const']['noisy_L'])
+    assert len(noisy_lengths) == 225
+
+    class OneDeadChannel(SyntheticModel):
+        """layer 15, channel 7 carries the same value at every residue (a dead unit of the language model)."""
+        def esm_encoder(self, tokens, repr_layers=None, return_contacts=True):
+            out = super().esm_encoder(tokens, repr_layers, return_contacts)
+            out['representations'][15][..., 7] = 1.5
+            return out
+
+    def load_model(name, device):
+        m = OneDeadChannel()
+        m.to_device(device)
+        return m
+
+    monkeypatch.setattr(make_db, 'load_model', load_model)
+    L = min(n for n in noisy_lengths if n >= 90)               # a length at which the reference would NOT give the 0 block
+    rng = np.random.default_rng(3)
+    fa = str(tmp_path / 'dead.fasta')
+    with open(fa, 'w') as fh:
+        for pid, n in (('NOISY', L), ('OTHER', 130)):
+            fh.write(f'>{pid} synthetic\n' + ''.join('ACDEFGHIKLMNPQRSTVWY'[int(v)] for v in rng.integers(0, 20, size=n)) + '\n')
+    dbfile, log = str(tmp_path / 'dead'), str(tmp_path / 'dead.log')
+    make_db.main(['--fafile', fa, '--dbfile', dbfile, '--model', 'synthetic', '--cpu', '2', '--noindex', '--out', log])
+    text = open(log).read()
+    assert 'constant channel in' in text and 'NOISY' in text and 'OTHER' in text and '225 of the lengths' in text
+    z = np.load(dbfile + '-dct.npz')
+    assert (z['dct'][:, :240] == 0).all()                       # layer 15: every (domain) block is the 0 block
+    rows = z['dct'][:, 240:].reshape(-1, 3, 80)                 # layer 21 is untouched
+    assert ((rows == 127).sum(axis=2) == 1).all()
+    # the class itself, one protein per call (own handler: make_db's --out replaced the root logger's handlers)
+    seen = []
+    grab = logging.Handler()
+    grab.emit = lambda record: seen.append(record.getMessage())
+    logging.getLogger().addHandler(grab)
+    try:
+        x = np.random.default_rng(4).standard_normal((L, 640)).astype(np.float32)
+        x[:, 11] = -0.25
+        fp = dd.Fingerprint(pid='ONE', seq='A' * L, embed={0: x}, domains=[f'1-{L}'])
+        fp.quantize([3, 80])
+        assert any('constant channel in ONE' in m for m in seen)
+        assert (fp.quants[f'1-{L}'] == 0).all()
+        del seen[:]
+        y = x.copy()
+        y[:, 11] = x[:, 12]
+        fp = dd.Fingerprint(pid='FINE', seq='A' * L, embed={0: y}, domains=[f'1-{L}'])
+        fp.quantize([3, 80])
+        assert not any('constant channel' in m for m in seen)
+    finally:
+        logging.getLogger().removeHandler(grab)

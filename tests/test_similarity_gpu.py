@@ -83,3 +83,43 @@ def test_row_select_matches_stable_argsort():
         order = np.argsort(d, axis=1, kind='stable')[:, :k]
         np.testing.assert_array_equal(i, order)
         np.testing.assert_array_equal(v, np.take_along_axis(d, order, axis=1))
+
+
+def test_database_axis_tiling_and_proteins_without_fingerprints(tmp_path, monkeypatch):
+    """Both consumers tile the database side as well (query_db.COL_ROWS / dct_sim.Blocks.COL_ROWS): tiny tiles must give
+    the same answers as one tile; a protein with zero fingerprints in the npz (an empty stripe, data_ptr() == 0) must not
+    reach the kernels."""
+    from dctdomain_amd import dct_sim, query_db
+    rng = np.random.default_rng(8)
+    counts = [3, 0, 2, 5, 0, 0, 4, 1]                               # proteins 1, 4, 5: no fingerprint at all
+    idx = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    dct = rng.integers(0, 128, size=(int(idx[-1]), 480)).astype(np.int8)
+    sid = np.array([f'p{i}' for i in range(len(counts))])
+    f = str(tmp_path / 'gaps-dct.npz')
+    np.savez(f, sid=sid, idx=idx, dom=np.array(['1-9'] * int(idx[-1])), dct=dct)
+    whole = dct_sim.Blocks(f)
+    d = np.abs(dct.astype(np.int64)[:, None, :] - dct.astype(np.int64)[None, :, :]).sum(-1)
+    for i in range(len(counts)):
+        for j in range(len(counts)):
+            blk = d[idx[i]:idx[i + 1], idx[j]:idx[j + 1]]
+            if blk.size:
+                assert whole.mn[i, j] == blk.min() and whole.last[i, j] == blk[-1, -1]
+            else:
+                assert whole.mn[i, j] == 0x7fffffff and whole.last[i, j] == 0x7fffffff
+    monkeypatch.setattr(dct_sim.Blocks, 'COL_ROWS', 4)
+    monkeypatch.setattr(dct_sim.Blocks, 'TILE_INTS', 12)
+    tiled = dct_sim.Blocks(f)
+    np.testing.assert_array_equal(tiled.mn, whole.mn)
+    np.testing.assert_array_equal(tiled.last, whole.last)
+    # query side: k nearest over database blocks of 7 rows == over the whole database
+    q = rng.integers(0, 128, size=(9, 480)).astype(np.int8)
+    db = rng.integers(0, 4, size=(40, 480)).astype(np.int8)         # few distinct values: many distance ties
+    qrows = [(i, f'q{i % 3}', '1-9') for i in range(len(q))]
+    drows = [(i, f'd{i}', '1-9') for i in range(len(db))]
+    one = list(query_db.search(qrows, q, drows, db, 12))
+    monkeypatch.setattr(query_db, 'COL_ROWS', 7)
+    monkeypatch.setattr(query_db, 'TILE_INTS', 21)
+    assert list(query_db.search(qrows, q, drows, db, 12)) == one
+    dist = np.abs(q.astype(np.int64)[:, None, :] - db.astype(np.int64)[None, :, :]).sum(-1)
+    top = round(1 - dist[[0, 3, 6]].min() / 17000, 4)                # protein q0 = query rows 0, 3, 6
+    assert [ln for ln in one if ln.startswith('Query: q0')][0].endswith(f'Similarity: {top}')
