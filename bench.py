@@ -191,7 +191,13 @@ def main():
     elapsed = time.perf_counter() - t0
     ms_k, n_k = ctx.profile()                       # hipEvent time of stage A / stage B on the launch stream
     ctx.set_option('profile', 0)
+    own_elapsed = elapsed
     elapsed = ddist.max_over_ranks(elapsed, device if args.backend == 'nccl' else None)
+    # (the line reports max-over-ranks as the contract says; min and the rank-local kernel time make a bad curve readable)
+    fastest = -ddist.max_over_ranks(-own_elapsed, device if args.backend == 'nccl' else None)
+    own_kernel_ms = ms_k[0] / max(1, n_k[0])
+    slowest_kernel_ms = ddist.max_over_ranks(own_kernel_ms, device if args.backend == 'nccl' else None)
+    fastest_kernel_ms = -ddist.max_over_ranks(-own_kernel_ms, device if args.backend == 'nccl' else None)
     fp_all_ranks = ddist.sum_over_ranks(n_fp, device if args.backend == 'nccl' else None)   # ragged workloads differ per rank
 
     # ---- parity sample against the oracle (checker only; outside the timed region) ----
@@ -245,14 +251,14 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': {
-                'c2': f'C2: {n_seq} sequences/GPU x {args.layers} layers of L={L} x D={D} float32 (ESM-like '
+                'c2': f'C2: {n_seq} sequences/GPU x {args.layers} layers of L={L} x D={D} {args.storage} (ESM-like '
                       f'synthetic), one whole-sequence domain each, qdim [3,80]x{args.layers} -> '
                       f'{240 * args.layers} int8 per fingerprint',
-                'c3': f'C3: {n_seq} sequences/GPU, L ~ U[50,2000] ({total_rows} rows), D={D}, {args.layers} layers, '
+                'c3': f'C3: {n_seq} sequences/GPU, L ~ U[50,2000] ({total_rows} rows), D={D} {args.storage}, {args.layers} layers, '
                       f'whole-sequence domains, ragged batch',
-                'c4': f'C4: {n_seq} sequences/GPU, L ~ U[100,500], D={D}, {args.layers} layers, 1-6 domains + whole '
+                'c4': f'C4: {n_seq} sequences/GPU, L ~ U[100,500], D={D} {args.storage}, {args.layers} layers, 1-6 domains + whole '
                       f'protein ({n_fp} fingerprints)',
-                'c5': f'C5 mix: {n_seq} sequences/GPU, pfam-like lengths 81-1330, D={D}, {args.layers} layers, '
+                'c5': f'C5 mix: {n_seq} sequences/GPU, pfam-like lengths 81-1330, D={D} {args.storage}, {args.layers} layers, '
                       f'~110-residue domains + whole protein ({n_fp} fingerprints)'}[args.workload],
                        'sequences_per_gpu': n_seq, 'fingerprints_per_gpu': n_fp, 'L': L if args.workload == 'c2' else None,
                        'D': D, 'layers': args.layers, 'sharding': f'seq{world}'},
@@ -262,6 +268,8 @@ def main():
                          'algorithmic_bytes_per_launch': a_bytes,
                          'stage_b_avg_launch_ms': ms_k[1] / max(1, n_k[1]),
                          'whole_path_GBps': value / world * bytes_per_fp / 1e9},
+            'per_rank_ms': {'step': [1e3 * fastest / args.steps, 1e3 * elapsed / args.steps],
+                            'kernel_launch': [fastest_kernel_ms, slowest_kernel_ms]},      # [min, max] over the ranks
             'cpu_baseline': cpu_baseline,
             'parity': parity,
             'per_layer_fingerprints_per_s': value * args.layers,   # 240-byte matrix fingerprints, same GB/s

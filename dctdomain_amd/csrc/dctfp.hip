@@ -213,7 +213,9 @@ struct dctfp_ctx {
     uint32_t* flag_host = nullptr;             // pinned + mapped word the kernels set when they see one (option degenerate_seen)
     int n_cu = 256;  // compute units of the device (workgroup slots of the walk kernel = n_cu x workgroups per CU)
     int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0;
+    int64_t opt_ab_narrow = 0;  // walk kernel at D <= 640: 0 / 1 = five waves x 2 channels per lane, 2 = three waves x 4 (A/B)
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
+    int64_t walk_launches = 0;  // walk-kernel launches so far (a call split at a giant domain ends on the two-kernel path)
     int64_t test_fail_once = 0;                    // test hook: the next dctfp_quantize fails after its table lookups
     int64_t basis_cap_doubles = (int64_t)1 << 27;  // 1 GiB of cosine tables, then the arena starts over (test hook: basis_cap_kb)
     int64_t basis_restarts = 0;                    // how often it did
@@ -326,7 +328,8 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
                 tab[(size_t)d * 80 + 40 + c] = (m - 1 - c == c) ? 0.0 : (double)co[c];
             }
         }
-        std::vector<double> fr((size_t)e.frag_groups * nt * 256, 0.0);
+        // (two groups of zeros behind the last one: the flush requests its fragments a few k-steps ahead without a clamp)
+        std::vector<double> fr((size_t)(e.frag_groups + 2) * nt * 256, 0.0);
         for (int q = 0; q < e.frag_groups; ++q)
             for (int r = 0; r < 4; ++r)
                 for (int c = 0; c < nt; ++c)
@@ -563,14 +566,14 @@ struct WParams {
     hipStream_t stream;
 };
 
-template <typename T, int S, int G, int NT, int UNROLL>
+template <typename T, int S, int G, int NT, int UNROLL, int VEC = 4>
 void launch_walk_impl(const WParams& p, bool fused) {
     static const InvTab<3> inv = make_inv<3>();
     if (fused)
-        hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
+        hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true, VEC>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
                            p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
     else
-        hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, false>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
+        hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, false, VEC>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
                            p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
 }
 
@@ -589,7 +592,12 @@ int launch_walk_u(const WParams& p, int unroll, bool fused) {
 // Instantiated shapes: S waves cover up to 256 S channels; G = jobs per flush <= 4 (the rows of an MFMA tile), bounded by
 // the LDS too (2304 B per wave and job: G = 4 leaves room for 17 waves per CU, G = 3 for 23).  A flush costs the same
 // MFMAs for 1..4 jobs, so G = 4 is the default everywhere.  Half-precision rows: the default shape only.
-int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fused) {
+int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fused, int vec) {
+    if (vec == 2) {  // float32 rows at D <= 640: five waves of 128 channels, 8 bytes per lane, 16 rows in flight
+        if (dtype != DCTFP_F32 || s != 5 || g != 4) return fail(DCTFP_ERR_INVALID, "walk kernel: the 2-channel shape is float32, 5 waves, 4 jobs per flush");
+        launch_walk_impl<float, 5, 4, 5, 16, 2>(p, fused);
+        return DCTFP_OK;
+    }
     if (dtype == DCTFP_F16 || dtype == DCTFP_BF16) {
         const bool h = dtype == DCTFP_F16;
         if (s == 3) h ? launch_walk_impl<_Float16, 3, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 3, 4, 5, 8>(p, fused);
@@ -749,6 +757,9 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "ab_longest_first") {
         if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "ab_longest_first must be 0 (auto), 1 (on) or 2 (off)");
         ctx->opt_ab_longest_first = value;
+    } else if (n == "ab_narrow") {
+        if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "ab_narrow must be 0 (auto), 1 (on) or 2 (off)");
+        ctx->opt_ab_narrow = value;
     } else if (n == "ab_run_jobs") {
         if (value < 0 || value > 4096) return fail(DCTFP_ERR_INVALID, "ab_run_jobs must be 0 (auto) .. 4096");
         ctx->opt_ab_run_jobs = value;
@@ -787,9 +798,11 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     else if (n == "overlap") *value = ctx->opt_overlap;
     else if (n == "path") *value = ctx->opt_path;
     else if (n == "last_path") *value = ctx->last_path;
+    else if (n == "walk_launches") *value = ctx->walk_launches;
     else if (n == "ab_group") *value = ctx->opt_ab_group;
     else if (n == "ab_unroll") *value = ctx->opt_ab_unroll;
     else if (n == "ab_run_jobs") *value = ctx->opt_ab_run_jobs;
+    else if (n == "ab_narrow") *value = ctx->opt_ab_narrow;
     else if (n == "ab_longest_first") *value = ctx->opt_ab_longest_first;
     else if (n == "small_b_jobs") *value = ctx->opt_small_b_jobs;
     else if (n == "degenerate_channels") {  // synchronises the device
@@ -847,19 +860,22 @@ int dctfp_profile(dctfp_ctx* ctx, double ms[2], int64_t launches[2]) {
     return DCTFP_OK;
 }
 
-int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, int32_t n_seq,
-                   const int64_t* seq_rows, const dctfp_piece* pieces, int64_t n_pieces, int64_t n_domains,
-                   int8_t* out, int64_t out_stride, void* stream_v) {
-    if (!ctx) return fail(DCTFP_ERR_INVALID, "dctfp_quantize: ctx is NULL");
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    if (n_layers < 0 || n_seq < 0 || n_pieces < 0 || n_domains < 0)
-        return fail(DCTFP_ERR_INVALID, "dctfp_quantize: negative count");
-    if (n_layers == 0 || n_domains == 0) return DCTFP_OK;
-    if (!layers || !seq_rows || !pieces || !out) return fail(DCTFP_ERR_INVALID, "dctfp_quantize: NULL argument");
-    if (n_pieces >= (int64_t)1 << 31 || n_domains >= (int64_t)1 << 31)
-        return fail(DCTFP_ERR_LIMIT, "dctfp_quantize: more than 2^31 pieces or domains in one call");
-    hipStream_t stream = (hipStream_t)stream_v;
-    HIP_TRY(hipSetDevice(ctx->device));
+}  // extern "C"
+
+namespace {
+
+constexpr uint32_t kWalkMaxRows = 8192;  // longest domain a wave of the walk kernel streams on its own
+
+// Shapes the walk kernel takes (the rest of its conditions -- alignment, job count -- are judged per call in quantize_impl).
+bool walk_shape(const dctfp_layer& ly) {
+    return ly.n_keep == 3 && ly.m_keep > 64 && ly.m_keep <= 80 && ly.dtype != DCTFP_F64 && ly.n_cols >= 512 && ly.n_cols <= 2560;
+}
+
+// dctfp_quantize proper.  `out_row` (optional): the output row of every domain of THIS piece table (a call that
+// dctfp_quantize has split in two); without it domain d writes row d.  The caller holds the context's mutex.
+int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, int32_t n_seq, const int64_t* seq_rows,
+                  const dctfp_piece* pieces, int64_t n_pieces, int64_t n_domains, int8_t* out, int64_t out_stride,
+                  hipStream_t stream, const int64_t* out_row) {
 
     // ---- validate the piece table, domain lengths --------------------------------
     std::vector<uint32_t> dom_len((size_t)n_domains, 0), dom_first((size_t)n_domains, 0), dom_np((size_t)n_domains, 0);
@@ -1030,7 +1046,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             const dctfp_layer& ly = layers[l0 + li];
             for (int64_t d = 0; d < n_domains; ++d) {
                 const int64_t job = (int64_t)li * n_domains + d;
-                hjb[job].out_off = d * out_stride + ly.out_offset;
+                hjb[job].out_off = (out_row ? out_row[d] : d) * out_stride + ly.out_offset;
                 hja[job].piece_begin = (uint32_t)((int64_t)li * n_pieces + dom_first[d]);
                 hja[job].n_pieces = dom_np[d];
                 hja[job].n_rows = dom_len[d];
@@ -1074,8 +1090,9 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         // 512 <= D <= 2560, no giant domain
         // (a wave streams all rows of its channels).  Everything else runs stage A -> Y' -> stage B.
         const bool half_rows = g.dtype == DCTFP_F16 || g.dtype == DCTFP_BF16;  // (their `vec` is 8, or 4 for fused walks: the walk kernel reads 4)
-        const bool walk_ok = !trivial && n == 3 && m > 64 && m <= 80 && ((g.dtype == DCTFP_F32 && vec == 4) || (half_rows && vec >= 4)) && g.n_cols >= 512 &&
-                             g.n_cols <= 2560 && max_len_all <= 8192 && ctx->opt_stage_b == 1;
+        // (rows are addressed through a 32-bit buffer offset: a piece of at most kWalkMaxRows rows stays below 2^31 bytes)
+        const bool walk_ok = !trivial && walk_shape(g) && ((g.dtype == DCTFP_F32 && vec == 4) || (half_rows && vec >= 4)) &&
+                             max_len_all <= kWalkMaxRows && (size_t)g.ld * esz <= ((size_t)1 << 31) / kWalkMaxRows && ctx->opt_stage_b == 1;
         // Measured (profiles/r02): the walk kernel wins at every width it takes -- D = 2560 (10-wave workgroups, one per CU)
         // since its flush contracts the even and odd halves of the basis apart: 5.3 against 4.9-5.25 TB/s on config 4.
         // A small call (a protein at a time, the reference's calling pattern) is latency-bound: there the two-kernel path,
@@ -1083,11 +1100,18 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         const bool use_walk = walk_ok && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 256));
         // walks of ALL jobs (walk kernel) -- the two-kernel path builds its walks per chunk below
         int64_t n_walks = 0, n_runs = 0;
-        int walk_s = 0, walk_g = 0;
+        int walk_s = 0, walk_g = 0, walk_vec = 4;
         if (use_walk) {
             walk_s = g.n_cols <= 768 ? 3 : (g.n_cols <= 1280 ? 5 : 10);
             // jobs per flush: 4 = the rows of an MFMA tile (a flush costs the same MFMAs for 1..4 jobs)
             walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : 4;
+            // D <= 640 (esm2_t30, the reference's own model): three waves of 256 channels leave half of the third wave
+            // streaming padding -- a sixth of the issue slots.  Five waves of 128 channels (2 per lane, 8-byte loads of the
+            // same two 256-byte row segments per wave) are all full.
+            if (g.dtype == DCTFP_F32 && g.n_cols <= 640 && walk_g == 4 && ctx->opt_ab_narrow == 1) {
+                walk_s = 5;
+                walk_vec = 2;
+            }
             for (int64_t j = 0; j < n_jobs;) {
                 const int64_t d = j % n_domains;
                 Walk& wk = hwalk[n_walks++];
@@ -1121,7 +1145,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
                 const int64_t by_rows = job_rows >= 384 ? 1 : 4 * walk_g;
                 if (ctx->opt_ab_longest_first == 0) longest_first = by_rows >= walk_g && walk_s == 10;
                 // workgroups the chip holds at once (LDS: 5 / 3 / 1 per CU at 3 / 5 / 10 waves)
-                const int64_t slots = (int64_t)ctx->n_cu * (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));
+                const int64_t slots = (int64_t)ctx->n_cu * (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));  // (5 waves of 2 channels: 41 KB, 3 too)
                 if (n_jobs <= 6 * slots * by_rows) {
                     // fewer than a handful of rounds at that size: ONE round of equal workgroups instead (a second, partly
                     // filled round costs as much as a full one: 1 024 whole-protein jobs 509 us as 1 024 workgroups, 477 as 512)
@@ -1333,6 +1357,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         if (ctx->basis_valid && ctx->basis_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_basis, 0));
 
         ctx->last_path = use_walk ? 2 : 1;
+        ctx->walk_launches += use_walk ? 1 : 0;
         if (use_walk) {
             // one launch: stage A + stage B per workgroup, int8 out
             EventPair* ep = nullptr;
@@ -1352,7 +1377,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
             wp.degenerate = ctx->degenerate;
             wp.grid = (unsigned)n_runs;
             wp.stream = stream;
-            rc = launch_walk(wp, g.dtype, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : 8, fuse);
+            rc = launch_walk(wp, g.dtype, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : 8, fuse, walk_vec);
             if (rc) return rc;
             HIP_TRY(hipGetLastError());
             rc = prof_end(ep, stream);
@@ -1502,6 +1527,64 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         l0 = l1;
     }
     return DCTFP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, int32_t n_seq,
+                   const int64_t* seq_rows, const dctfp_piece* pieces, int64_t n_pieces, int64_t n_domains,
+                   int8_t* out, int64_t out_stride, void* stream_v) {
+    if (!ctx) return fail(DCTFP_ERR_INVALID, "dctfp_quantize: ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_layers < 0 || n_seq < 0 || n_pieces < 0 || n_domains < 0)
+        return fail(DCTFP_ERR_INVALID, "dctfp_quantize: negative count");
+    if (n_layers == 0 || n_domains == 0) return DCTFP_OK;
+    if (!layers || !seq_rows || !pieces || !out) return fail(DCTFP_ERR_INVALID, "dctfp_quantize: NULL argument");
+    if (n_pieces >= (int64_t)1 << 31 || n_domains >= (int64_t)1 << 31)
+        return fail(DCTFP_ERR_LIMIT, "dctfp_quantize: more than 2^31 pieces or domains in one call");
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    // A domain above kWalkMaxRows rows (a titin in a flush of 10 000 proteins) must not take the whole call off the walk
+    // kernel: such domains are cut out into a call of their own (two-kernel path), everything else stays where it was.
+    // Only when every layer has the walk kernel's shape and the rest of the call is large enough to be sent there.
+    bool all_walk = ctx->opt_path != 1;
+    for (int32_t l = 0; l < n_layers && all_walk; ++l) all_walk = walk_shape(layers[l]);
+    if (all_walk && n_domains * n_layers >= 256) {
+        std::vector<uint32_t> len((size_t)n_domains, 0);
+        bool table_ok = true;
+        for (int64_t i = 0; i < n_pieces && table_ok; ++i) {
+            const dctfp_piece& pc = pieces[i];
+            table_ok = pc.domain >= 0 && pc.domain < n_domains && pc.n_rows > 0 && (uint64_t)len[pc.domain] + (uint64_t)pc.n_rows <= 0x7fffffffu;
+            if (table_ok) len[pc.domain] += (uint32_t)pc.n_rows;
+        }
+        int64_t n_giant = 0;
+        for (int64_t d = 0; d < n_domains && table_ok; ++d) n_giant += len[d] > kWalkMaxRows ? 1 : 0;
+        if (table_ok && n_giant > 0 && n_giant < n_domains) {  // (a broken table goes to quantize_impl as it is: it reports the error)
+            std::vector<dctfp_piece> part[2];
+            std::vector<int64_t> rows[2], new_id((size_t)n_domains);
+            for (int64_t d = 0; d < n_domains; ++d) {
+                const int w = len[d] > kWalkMaxRows ? 1 : 0;
+                new_id[d] = (int64_t)rows[w].size();
+                rows[w].push_back(d);
+            }
+            for (int64_t i = 0; i < n_pieces; ++i) {
+                dctfp_piece pc = pieces[i];
+                const int w = len[pc.domain] > kWalkMaxRows ? 1 : 0;
+                pc.domain = (int32_t)new_id[pc.domain];
+                part[w].push_back(pc);
+            }
+            for (int w = 0; w < 2; ++w) {
+                const int rc = quantize_impl(ctx, layers, n_layers, n_seq, seq_rows, part[w].data(), (int64_t)part[w].size(),
+                                             (int64_t)rows[w].size(), out, out_stride, stream, rows[w].data());
+                if (rc) return rc;
+            }
+            return DCTFP_OK;
+        }
+    }
+    return quantize_impl(ctx, layers, n_layers, n_seq, seq_rows, pieces, n_pieces, n_domains, out, out_stride, stream, nullptr);
 }
 
 int dctfp_idct_quant(dctfp_ctx* ctx, const void* vec, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,

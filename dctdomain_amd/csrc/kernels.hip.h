@@ -23,6 +23,7 @@ namespace dctfp {
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 typedef unsigned short v4us __attribute__((ext_vector_type(4)));
@@ -130,6 +131,8 @@ struct Raw;
 template <>
 struct Raw<float, 4> { typedef v4f type; };
 template <>
+struct Raw<float, 2> { typedef v2f type; };  // 8 bytes per lane: the walk kernel at D <= 640 (five full waves instead of 2.5 of 3)
+template <>
 struct Raw<float, 1> { typedef float type; };
 template <>
 struct Raw<double, 2> { typedef v2d type; };
@@ -154,6 +157,26 @@ __device__ inline typename Raw<T, VEC>::type load_raw(const T* p) {
     typedef typename Raw<T, VEC>::type R;
     typedef const R __attribute__((address_space(1))) * GP;
     return __builtin_nontemporal_load((GP)(uintptr_t)p);  // +6..8 % over the default cache policy (profiles/r01)
+}
+// The same through a buffer descriptor: base in scalar registers, ONE 32-bit lane offset for every load of a piece, the row
+// (or table step) offset in a scalar register -- no 64-bit address arithmetic on the vector pipe and no address registers
+// (the walk kernel issues a load per 25 vector instructions and its flush wants many fragment loads in flight).
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+__device__ inline __amdgpu_buffer_rsrc_t wave_buffer(const void* base) {  // `base` must be wave-uniform; no range check
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+template <typename R, bool NT>
+__device__ inline R buffer_load_raw(__amdgpu_buffer_rsrc_t rs, int lane_bytes, int uniform_bytes) {
+    constexpr int aux = NT ? 2 : 0;  // gfx94x / gfx950 cache-policy bits: 2 = nt
+    if constexpr (sizeof(R) == 16) {
+        const v4u32 r = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes, uniform_bytes, aux);
+        return __builtin_bit_cast(R, r);
+    } else {
+        static_assert(sizeof(R) == 8, "8 or 16 bytes per lane");
+        const v2u32 r = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_bytes, uniform_bytes, aux);
+        return __builtin_bit_cast(R, r);
+    }
 }
 // Element v of a raw image as float64 (every storage type converts exactly).
 template <typename T, int VEC, typename R>
@@ -929,6 +952,34 @@ __global__ __launch_bounds__(256) void stage_b_finish_kernel(const double* __res
 //           of a k-step follow each other.  The pair order inside a group (k = 4 (lane >> 4) + r) is the one the packed
 //           Y' is read in.
 // ---------------------------------------------------------------------------
+// Minimum and maximum over the lanes 0 .. 47 of a wave (a fingerprint row: m <= 80 values, two per lane in lanes < 40) by
+// DPP rotations inside the 16-lane rows and three v_readlane per value -- a dependent chain of ~20 short instructions where
+// the xor-shuffle (ds_bpermute: a trip through the LDS crossbar per level and value) took most of the 1 500+ cycles a
+// fingerprint row cost the wave that wrote it.  Lanes without a value pass +inf / -inf.
+template <int CTRL>
+__device__ inline double dpp_rotate(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double lane_value(double v, int src_lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+__device__ inline void wave_min_max48(double& mn, double& mx) {
+    // row_ror:8, 4, 2, 1 -> every lane of a 16-lane row holds the row's extremes
+    mn = fmin(mn, dpp_rotate<0x128>(mn));
+    mx = fmax(mx, dpp_rotate<0x128>(mx));
+    mn = fmin(mn, dpp_rotate<0x124>(mn));
+    mx = fmax(mx, dpp_rotate<0x124>(mx));
+    mn = fmin(mn, dpp_rotate<0x122>(mn));
+    mx = fmax(mx, dpp_rotate<0x122>(mx));
+    mn = fmin(mn, dpp_rotate<0x121>(mn));
+    mx = fmax(mx, dpp_rotate<0x121>(mx));
+    mn = fmin(fmin(lane_value(mn, 0), lane_value(mn, 16)), lane_value(mn, 32));
+    mx = fmax(fmax(lane_value(mx, 0), lane_value(mx, 16)), lane_value(mx, 32));
+}
+
 struct Run {
     uint32_t walk_begin;  // first Walk of this workgroup
     uint32_t n_walks;
@@ -936,15 +987,17 @@ struct Run {
     uint32_t n_jobs;
 };
 
-constexpr int kWalkChannels = 256;  // channels per wave: 64 lanes x 4 float32
 
 // Build-time knobs of the walk kernel (A/B builds: tools/build_variant.sh).
 #ifndef DCTFP_WALK_MIN_WAVES
 #define DCTFP_WALK_MIN_WAVES 4       // waves per SIMD the register allocation is held to (4 -> 128 VGPRs)
 #endif
+#ifndef DCTFP_WALK_ASYNC
+#define DCTFP_WALK_ASYNC 0           // 1: no workgroup barrier in a flush, the last wave to arrive finishes the rows (experiment)
+#endif
 #ifndef DCTFP_WALK_B_DEPTH
-#define DCTFP_WALK_B_DEPTH 1         // k-steps of stage-B fragments in flight during a flush (1, 2, 4); more was never faster:
-#endif                               // what a flush costs is issue time, not L2 latency (profiles/r02/experiments/flush_*)
+#define DCTFP_WALK_B_DEPTH 0         // k-steps of stage-B fragments in flight during a flush: 0 = by shape (below), else 1, 2, 4
+#endif
 
 // Instrumented build (tools/walk_timeline.py; never the shipped library): every wave adds the shader-clock cycles it
 // spends per phase to degenerate[1 + phase] -- 0 stream (job record -> last row accumulated), 1 epilogue, 2 flush
@@ -970,17 +1023,27 @@ constexpr int kWalkChannels = 256;  // channels per wave: 64 lanes x 4 float32
 #define DCTFP_TL_ANCHOR(x)
 #endif
 
-template <typename T, int S, int G, int NT, int UNROLL, bool FUSED>
+template <typename T, int S, int G, int NT, int UNROLL, bool FUSED, int VEC = 4>
 __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
                                                           const Walk* __restrict__ walks, const Run* __restrict__ runs,
                                                           const PieceA* __restrict__ pieces, const double* __restrict__ stf,
                                                           int8_t* __restrict__ out, int n_cols, int64_t ld, int m,
                                                           InvTab<3> inv, unsigned long long* __restrict__ degenerate) {
-    constexpr int VEC = 4, NK = 2;
-    // per wave and slot: 256 t values (later reused for the wave's partial 3 x (NT*16) block) + 256 state bytes
-    __shared__ double lds_t[S][G][kWalkChannels];
-    __shared__ uint32_t lds_c[S][G][kWalkChannels / 4];
-    static_assert(3 * NT * 16 <= kWalkChannels, "partial Z block must fit the slot it reuses");
+    constexpr int NK = 2;
+    static_assert(VEC == 4 || (VEC == 2 && sizeof(T) == 4), "4 channels per lane, or 2 of float32 (D <= 640)");
+    constexpr int WCH = 64 * VEC;  // channels per wave: 256 (or 128: VEC = 2)
+    // per wave and slot: WCH t values (later reused for the wave's partial 3 x (NT*16) block) + WCH state bytes
+    constexpr int SLOT = WCH > 3 * NT * 16 ? WCH : 3 * NT * 16;
+    __shared__ double lds_t[S][G][SLOT];
+    __shared__ __attribute__((aligned(4))) uint8_t lds_c[S][G][WCH];
+    // No workgroup barrier per flush: [0] counts the waves that have left their partial blocks in LDS (over all flushes so
+    // far), [1] the flushes whose cross-wave sum is done -- see "flush" below.
+    __shared__ uint32_t lds_sync[2];
+    if (threadIdx.x == 0) {
+        lds_sync[0] = 0;
+        lds_sync[1] = 0;
+    }
+    __syncthreads();  // (the only one of the kernel)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -989,7 +1052,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
     // images -- two 512-byte segments of every row (as fast as one of 1 KiB: tools/microbench/read_ceiling.hip) -- so that
     // the even/odd fold of the flush finds both channels of a pair in the wave's own slots.
     const int half = n_cols >> 1;
-    const int pair0 = wave * (kWalkChannels / 2) + VEC * (lane & 31);  // the first of my 4 pairs
+    const int pair0 = wave * (WCH / 2) + VEC * (lane & 31);  // the first of my VEC pairs
     const bool mirror = lane >= 32;
     const bool pad = pair0 >= half;  // out-of-range lanes stream column 0 and are discarded
     const int colc = pad ? 0 : (mirror ? n_cols - VEC - pair0 : pair0);
@@ -997,11 +1060,16 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
     // each pair once -- and the degenerate-channel counter must see each channel once
     auto channel_counts = [&](int v) { return !pad && pair0 + (mirror ? VEC - 1 - v : v) < half; };
     // 16-pair groups of this wave that hold real pairs
-    const int n_q = min(kWalkChannels / 32, max(0, (half + 15) / 16 - wave * (kWalkChannels / 32)));
-    typedef typename Raw<T, 4>::type Rw;  // 4 channels per lane: 16 bytes of float32, 8 of float16 / bfloat16
+    const int n_q = min(WCH / 32, max(0, (half + 15) / 16 - wave * (WCH / 32)));
+    typedef typename Raw<T, VEC>::type Rw;  // 4 channels per lane: 16 bytes of float32, 8 of float16 / bfloat16 (VEC = 2: 8 of float32)
+    const int col_bytes = colc * (int)sizeof(T);       // my lane's offset inside every row
+    const int ld_bytes = (int)(ld * (int64_t)sizeof(T));  // (the host sends only layers whose pieces stay below 2^31 bytes here)
 
     uint32_t pending = 0;            // jobs whose Y' sits in LDS
     uint32_t group_job = run.job_begin;  // job of slot 0
+#if DCTFP_WALK_ASYNC
+    uint32_t n_flushed = 0;          // flushes this wave has contracted
+#endif
     DCTFP_TL_DECL
 
     for (uint32_t wi = 0; wi < run.n_walks; ++wi) {
@@ -1047,7 +1115,8 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 double cwsum[NK] = {0.0, 0.0};
                 auto stream_piece = [&](auto hw_tag, const PieceA& piece) {
                     constexpr bool HW = decltype(hw_tag)::value;
-                    const T* __restrict__ base = reinterpret_cast<const T*>(piece.ptr) + colc;
+                    const __amdgpu_buffer_rsrc_t rows = wave_buffer(piece.ptr);
+                    auto load_row = [&](uint32_t r) { return buffer_load_raw<Rw, true>(rows, col_bytes, (int)r * ld_bytes); };
                     const CosTab btp = cos_tab(job.basis) + (size_t)piece.t0 * NK;
                     const CosTab wtp = cos_tab(job.w_basis) + (size_t)piece.w0 * NK;
                     auto row_update = [&](const Rw& x, uint32_t r) {
@@ -1068,7 +1137,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                     for (; r + UNROLL <= piece.n_rows; r += UNROLL) {
                         Rw xv[UNROLL];
 #pragma unroll
-                        for (int u = 0; u < UNROLL; ++u) xv[u] = load_raw<T, VEC>(base + (size_t)(r + u) * ld);
+                        for (int u = 0; u < UNROLL; ++u) xv[u] = load_row(r + u);
 #pragma unroll
                         for (int u = 0; u < UNROLL; ++u) row_update(xv[u], r + u);
                     }
@@ -1077,7 +1146,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                             if (r + 4 > piece.n_rows) break;
                             Rw xv[4];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) xv[u] = load_raw<T, VEC>(base + (size_t)(r + u) * ld);
+                            for (int u = 0; u < 4; ++u) xv[u] = load_row(r + u);
 #pragma unroll
                             for (int u = 0; u < 4; ++u) row_update(xv[u], r + u);
                             r += 4;
@@ -1087,7 +1156,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                         Rw xv[3];
 #pragma unroll
                         for (int u = 0; u < 3; ++u)
-                            if (r + u < piece.n_rows) xv[u] = load_raw<T, VEC>(base + (size_t)(r + u) * ld);
+                            if (r + u < piece.n_rows) xv[u] = load_row(r + u);
 #pragma unroll
                         for (int u = 0; u < 3; ++u)
                             if (r + u < piece.n_rows) row_update(xv[u], r + u);
@@ -1123,21 +1192,34 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
             DCTFP_TL_ANCHOR(f[0][0]);
             DCTFP_TL_ANCHOR(f[1][VEC - 1]);
             DCTFP_TL_MARK(0);
+#if DCTFP_WALK_ASYNC
+            if (pending == 0 && n_flushed > 0) {
+                // my slots still hold my partial blocks of the last flush until its cross-wave sum is done (by the wave that
+                // arrived last).  A whole job has been streamed since I arrived: this wait is over before it starts, unless
+                // another wave of the workgroup lags a whole job behind.
+                while (__hip_atomic_load(&lds_sync[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_flushed)
+                    __builtin_amdgcn_s_sleep(4);
+                DCTFP_TL_MARK(3);
+            }
+#endif
             {
-                v4d t4;
+                double tv[VEC];
                 uint32_t c4 = 0;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     const double fk[NK] = {f[0][v], f[1][v]};
-                    double t;
                     unsigned code;
-                    scale_pack3(fk, inv, !channel_counts(v), t, code, degenerate);
-                    t4[v] = t;
+                    scale_pack3(fk, inv, !channel_counts(v), tv[v], code, degenerate);
                     c4 |= code << (8 * v);
                     __builtin_amdgcn_sched_barrier(0);  // one channel at a time (register pressure)
                 }
-                *reinterpret_cast<v4d*>(&lds_t[wave][pending][VEC * lane]) = t4;
-                lds_c[wave][pending][lane] = c4;
+                if constexpr (VEC == 4) {
+                    *reinterpret_cast<v4d*>(&lds_t[wave][pending][VEC * lane]) = (v4d){tv[0], tv[1], tv[2], tv[3]};
+                    *reinterpret_cast<uint32_t*>(&lds_c[wave][pending][VEC * lane]) = c4;
+                } else {
+                    *reinterpret_cast<v2d*>(&lds_t[wave][pending][VEC * lane]) = (v2d){tv[0], tv[1]};
+                    *reinterpret_cast<uint16_t*>(&lds_c[wave][pending][VEC * lane]) = (uint16_t)c4;
+                }
             }
             ++pending;
             DCTFP_TL_MARK(1);
@@ -1171,39 +1253,45 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 for (int jr = 0; jr < 3; ++jr)
 #pragma unroll
                     for (int c = 0; c < NT; ++c) acc[jr][c] = 0.0;
-                // B fragments of k-step (q, r): NT column groups x 8 bytes per lane
-                const double* __restrict__ sq = stf + (size_t)wave * (kWalkChannels / 32) * 4 * NT * 64 + lane;
+                // B fragments of k-step (q, r): NT column groups x 8 bytes per lane.  The wave's part of the table is a uniform
+                // base (scalar registers), the lane adds 8 bytes: one address register for the whole flush.
+                const __amdgpu_buffer_rsrc_t frag = wave_buffer(stf + (size_t)wave * (WCH / 32) * 4 * NT * 64);
                 auto fetch_b = [&](double (&b)[NT], int step) {
 #pragma unroll
-                    for (int c = 0; c < NT; ++c) b[c] = sq[((size_t)step * NT + c) * 64];
+                    for (int c = 0; c < NT; ++c) b[c] = buffer_load_raw<double, false>(frag, lane * 8, (step * NT + c) * 512);
                 };
                 // DEPTH k-steps of fragments are in flight ahead of their use: a slot is refilled for step + DEPTH right after
-                // its MFMAs.  Past the end the last step is fetched again (no branch, static vmcnt).
-                constexpr int DEPTH = DCTFP_WALK_B_DEPTH;
+                // its MFMAs.  The table ends with two groups of zeros (host: get_st), so the requests past the wave's last
+                // step need no clamp (they are never used).  What a flush waits for is this latency: with one step in flight a
+                // k-step took 2 600 cycles against 255 of its 15 MFMAs (tools/walk_timeline.py, profiles/r03).
+                // As deep as the registers allow without spilling (the loads go through a buffer descriptor: no address
+                // registers): 4 steps where the budget is 168 registers (10 waves), 2 where the kernel carries no second accumulator set.
+                constexpr int DEPTH = DCTFP_WALK_B_DEPTH ? DCTFP_WALK_B_DEPTH : (S >= 10 ? 4 : (FUSED ? 1 : 2));
                 static_assert(DEPTH == 1 || DEPTH == 2 || DEPTH == 4, "slot of a k-step must be static under the 4-step unroll");
                 double bq[DEPTH][NT];
-                const int last_step = 4 * n_q - 1;
                 if (n_q > 0) {
 #pragma unroll
                     for (int r = 0; r < DEPTH; ++r) fetch_b(bq[r], r);
                 }
                 for (int qi = 0; qi < n_q; ++qi) {
                     const int pl0 = 16 * qi + 4 * g4;  // my pairs of this group: pl0 + r
-                    const int p0 = wave * (kWalkChannels / 2) + pl0;
+                    const int p0 = wave * (WCH / 2) + pl0;
                     // pairs past D/2 (D % 32 != 0) get state 0 = value 0, whatever the slots hold: byte r of the word of the
-                    // channels d, byte 3 - r of the mirrors' word
+                    // channels d, byte r ^ (VEC - 1) of the mirrors' word (a mirror lane holds its VEC channels in ascending
+                    // order: 3 - r, or r ^ 1 where D / 2 - p0 is even)
                     const int nl = min(4, max(0, half - p0));
                     const uint32_t lm = nl >= 4 ? 0xffffffffu : ((1u << (8 * nl)) - 1u);
-                    const uint32_t lmm = nl >= 4 ? 0xffffffffu : (nl <= 0 ? 0u : ~((1u << (8 * (4 - nl))) - 1u));
-                    const uint32_t cw = lds_c[wave][gs][pl0 >> 2] & lm;
-                    const uint32_t cwm = lds_c[wave][gs][32 + (pl0 >> 2)] & lmm;
+                    const uint32_t lmm = VEC == 2 ? lm : (nl >= 4 ? 0xffffffffu : (nl <= 0 ? 0u : ~((1u << (8 * (4 - nl))) - 1u)));
+                    const uint32_t cw = *reinterpret_cast<const uint32_t*>(&lds_c[wave][gs][pl0]) & lm;
+                    const uint32_t cwm = *reinterpret_cast<const uint32_t*>(&lds_c[wave][gs][WCH / 2 + pl0]) & lmm;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const double t = lds_t[wave][gs][pl0 + r], tm = lds_t[wave][gs][128 + pl0 + 3 - r];
+                        constexpr int RX = VEC - 1;  // position of pair r inside the mirror lanes' order
+                        const double t = lds_t[wave][gs][pl0 + r], tm = lds_t[wave][gs][WCH / 2 + pl0 + (r ^ RX)];
 #pragma unroll
                         for (int jr = 0; jr < 3; ++jr) {
                             const double y = unpack_bits(cw, 8 * r + 2 * jr, t);
-                            const double ym = unpack_bits(cwm, 8 * (3 - r) + 2 * jr, tm);
+                            const double ym = unpack_bits(cwm, 8 * (r ^ RX) + 2 * jr, tm);
                             const double au = y + ym, av = y - ym;
                             const double ax = fma(fold_sign, ym, y);  // blocks 0, 1 of the middle column group: u, blocks 2, 3: v
                             // 3 * NT independent accumulators between two uses of one
@@ -1211,7 +1299,10 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                             for (int c = 0; c < NT; ++c)
                                 acc[jr][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(c < 2 ? au : (c == 2 ? ax : av), bq[r % DEPTH][c], acc[jr][c], 0, 0, 0);
                         }
-                        fetch_b(bq[r % DEPTH], min(4 * qi + r + DEPTH, last_step));
+                        fetch_b(bq[r % DEPTH], 4 * qi + r + DEPTH);
+#ifdef DCTFP_FLUSH_SCHED_BARRIER
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
                     }
                 }
                 // partial blocks -> my slots (the Y' in them is consumed): tile row = lane >> 4 = job, zp[row jr][slot]
@@ -1224,50 +1315,68 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 }
             }
             DCTFP_TL_MARK(2);
+            // the three fingerprint rows of one job of the flush: sum over the waves in wave order, Z[c] = ZE[c] + ZO[c] and
+            // Z[m-1-c] = ZE[c] - ZO[c], per-row min-max scale, int8 (src/fingerprint.py:193-195); lane c < ceil(m / 2) holds both.
+            // The three rows go through together: their dependent chains (S additions, the DPP reduction, two divisions)
+            // interleave, so a job costs one wave little more than a single row did.
+            auto finish_job = [&](uint32_t g) {
+                const int hm = (m + 1) >> 1;
+                const bool valid0 = lane < hm;
+                const bool valid1 = lane < hm && (m - 1 - lane) != lane;  // odd m: the middle column is its own mirror (O = 0 there)
+                double v0[3], v1[3], mn[3], mx[3];
+                bool nan_here[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double ze = 0.0, zo = 0.0;
+                    if (valid0) {
+#pragma unroll
+                        for (int w = 0; w < S; ++w) {
+                            ze += lds_t[w][g][j * (NT * 16) + lane];
+                            zo += lds_t[w][g][j * (NT * 16) + 40 + lane];
+                        }
+                    }
+                    v0[j] = ze + zo;
+                    v1[j] = ze - zo;
+                    mn[j] = valid0 ? fmin(v0[j], valid1 ? v1[j] : v0[j]) : INFINITY;
+                    mx[j] = valid0 ? fmax(v0[j], valid1 ? v1[j] : v0[j]) : -INFINITY;
+                    nan_here[j] = valid0 && (v0[j] != v0[j] || v1[j] != v1[j]);
+                }
+                static_assert(DCTFP_MAX_M_K <= 128 && NT * 16 <= 80, "lanes 0 .. 39 hold a row");
+#pragma unroll
+                for (int j = 0; j < 3; ++j) wave_min_max48(mn[j], mx[j]);
+                int8_t* __restrict__ o = out + jobb[group_job + g].out_off;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const bool bad = __builtin_amdgcn_ballot_w64(nan_here[j]) != 0;  // a NaN anywhere in the row: the whole row is 0
+                    const double den = mx[j] - mn[j];
+                    if (valid0) o[j * m + lane] = quant127(v0[j] - mn[j], den, bad);
+                    if (valid1) o[j * m + m - 1 - lane] = quant127(v1[j] - mn[j], den, bad);
+                }
+            };
+#if DCTFP_WALK_ASYNC
+            // ---- no barrier: a wave that has left its partial blocks takes a ticket; whoever draws the last ticket of this
+            // flush finishes the rows.  Tickets are counted over all flushes: wave A cannot reach flush f + 1 before every wave
+            // has arrived at flush f, because A's next epilogue waits for the rows of flush f (above).
+            ++n_flushed;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            uint32_t ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&lds_sync[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+            if (ticket + 1 == n_flushed * (uint32_t)S) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                for (uint32_t g = 0; g < pending; ++g) finish_job(g);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every block has been read: the slots are free again
+                if (lane == 0) __hip_atomic_store(&lds_sync[1], n_flushed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                DCTFP_TL_MARK(4);
+            }
+#else
             __syncthreads();
             DCTFP_TL_MARK(3);
-            // sum over the waves in wave order, Z[c] = ZE[c] + ZO[c] and Z[m-1-c] = ZE[c] - ZO[c], per-row min-max scale, int8
-            // (src/fingerprint.py:193-195); lane c < ceil(m / 2) holds both
-            const int hm = (m + 1) >> 1;
-            for (uint32_t idx = (uint32_t)wave; idx < pending * 3u; idx += S) {
-                const uint32_t g = idx / 3u, j = idx - 3u * g;
-                double v[2] = {0.0, 0.0};
-                bool valid[2];
-                valid[0] = lane < hm;
-                valid[1] = lane < hm && (m - 1 - lane) != lane;  // odd m: the middle column is its own mirror (O = 0 there)
-                if (valid[0]) {
-                    double ze = 0.0, zo = 0.0;
-#pragma unroll
-                    for (int w = 0; w < S; ++w) {
-                        ze += lds_t[w][g][j * (NT * 16) + lane];
-                        zo += lds_t[w][g][j * (NT * 16) + 40 + lane];
-                    }
-                    v[0] = ze + zo;
-                    v[1] = ze - zo;
-                }
-                double mn = INFINITY, mx = -INFINITY;
-                int bad = 0;
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    if (valid[h]) {
-                        bad |= (v[h] != v[h]) ? 1 : 0;
-                        mn = fmin(mn, v[h]);
-                        mx = fmax(mx, v[h]);
-                    }
-#pragma unroll
-                for (int sft = 1; sft < 64; sft <<= 1) {
-                    mn = fmin(mn, __shfl_xor(mn, sft));
-                    mx = fmax(mx, __shfl_xor(mx, sft));
-                    bad |= __shfl_xor(bad, sft);
-                }
-                int8_t* __restrict__ o = out + jobb[group_job + g].out_off + (int64_t)j * m;
-                const double den = mx - mn;
-                if (valid[0]) o[lane] = quant127(v[0] - mn, den, bad != 0);
-                if (valid[1]) o[m - 1 - lane] = quant127(v[1] - mn, den, bad != 0);
-            }
+            for (uint32_t g = (uint32_t)wave; g < pending; g += S) finish_job(g);
             DCTFP_TL_MARK(4);
             __syncthreads();  // the slots are free again
             DCTFP_TL_MARK(5);
+#endif
             group_job += pending;
             pending = 0;
         }

@@ -29,6 +29,24 @@ import torch
 from .database import Database
 from .fingerprint import Fingerprint
 
+import time
+from collections import defaultdict
+from contextlib import contextmanager
+
+#: wall seconds per stage of the last ``run`` in this process (workers report theirs to the parent, which keeps the
+#: slowest worker's figure per stage): a build at scale says where its time went (profiles/r03/db_build_1M.txt)
+STAGE_SECONDS = defaultdict(float)
+
+
+@contextmanager
+def stage(name: str):
+    t0 = time.perf_counter()
+    try:
+        yield
+    finally:
+        STAGE_SECONDS[name] += time.perf_counter() - t0
+
+
 LAYERS = [15, 21]                 # src/make_db.py:78, :138
 QDIM = [3, 80, 3, 80]             # src/make_db.py:30
 THRESHOLD = 2.6                   # src/make_db.py:29
@@ -141,24 +159,31 @@ def process_sequences(seqs, model, device, maxlen: int, cpu: int, flush: int, si
     batch, cur = [], 0
 
     def run_batch(b):
-        bt = Batch(b, model, device)
-        bt.embed_batch(LAYERS, maxlen)
-        for emb in bt.embeds:
-            queue.append(Fingerprint(pid=emb.pid, seq=emb.seq, embed=emb.embed, contacts=emb.contacts))
+        with stage('embed (language model + window stitching)'):
+            bt = Batch(b, model, device)
+            bt.embed_batch(LAYERS, maxlen)
+            for emb in bt.embeds:
+                queue.append(Fingerprint(pid=emb.pid, seq=emb.seq, embed=emb.embed, contacts=emb.contacts))
+
+    def flush_queue():
+        with stage('fingerprint (contact top-k + RecCut + dctfp_quantize)'):
+            recs = _records(fingerprint_batch(queue, threads=cpu))
+        with stage('hand over to the writer'):
+            sink(recs)
+        queue.clear()
 
     for pid, seq in seqs:                          # same packing rule as Database.yield_seqs
         if batch and (cur + len(seq) > maxlen or len(batch) > cpu):
             run_batch(batch)
             batch, cur = [], 0
             if len(queue) >= flush:
-                sink(_records(fingerprint_batch(queue, threads=cpu)))
-                queue.clear()
+                flush_queue()
         batch.append((pid, seq))
         cur += len(seq)
     if batch:
         run_batch(batch)
     if queue:
-        sink(_records(fingerprint_batch(queue, threads=cpu)))
+        flush_queue()
 
 
 def _gpu_worker(rank: int, n_gpu: int, shards, model_name: str, maxlen: int, cpu: int, flush: int, out_q):
@@ -171,6 +196,7 @@ def _gpu_worker(rank: int, n_gpu: int, shards, model_name: str, maxlen: int, cpu
         torch.cuda.set_device(dev)
         model = load_model(model_name, dev)
         process_sequences(shards[rank], model, dev, maxlen, cpu, flush, lambda recs: out_q.put(('recs', rank, recs)))
+        out_q.put(('stats', rank, dict(STAGE_SECONDS)))
     except BaseException:       # noqa: BLE001 -- reported to the parent, which stops the build
         import traceback
         out_q.put(('error', rank, traceback.format_exc()))
@@ -204,6 +230,8 @@ def _run_workers(n_gpu: int, worker_args: tuple, sink, target=None, poll_s: floa
                                 late = out_q.get(timeout=0.5)
                                 if late[0] == 'recs':
                                     sink(late[2])
+                                elif late[0] == 'stats':
+                                    pass
                                 elif late[0] == 'done':
                                     finished.add(late[1])
                                 elif late[0] == 'error':
@@ -215,6 +243,9 @@ def _run_workers(n_gpu: int, worker_args: tuple, sink, target=None, poll_s: floa
                 continue
             if item[0] == 'recs':
                 sink(item[2])
+            elif item[0] == 'stats':
+                for k, v in item[2].items():
+                    STAGE_SECONDS[f'worker: {k}'] = max(STAGE_SECONDS[f'worker: {k}'], v)
             elif item[0] == 'error':
                 failure = f'GPU worker {item[1]} failed:\n{item[2]}'
             elif item[0] == 'done':
@@ -256,6 +287,10 @@ class OrderedWriter:
         self.written = 0
 
     def add(self, records):
+        with stage('writer: SQLite transactions'):
+            self._add(records)
+
+    def _add(self, records):
         for pid, domains, mat in records:
             self.held[self.order[pid]] = _Rec(pid, domains, mat)
         run = []
@@ -278,7 +313,9 @@ class OrderedWriter:
 def run(args: argparse.Namespace) -> Database:
     if args.out:
         logging.basicConfig(level=logging.INFO, filename=args.out, filemode='w', format='%(message)s', force=True)
-    db = Database(args.dbfile, args.fafile)
+    STAGE_SECONDS.clear()
+    with stage('open database + read FASTA'):
+        db = Database(args.dbfile, args.fafile)
     print('Fingerprinting sequences...\n')
     pending = db.pending()
     n_gpu = int(args.gpu) if args.gpu else 1
@@ -297,17 +334,24 @@ def run(args: argparse.Namespace) -> Database:
         shards = [[pending[i] for i in ix] for ix in idx]
         _run_workers(n_gpu, (shards, args.model, args.maxlen, cpu, args.flush), writer.add)
     # table order = pending order (ascending length) whatever the number of GPUs
-    writer.finish()
-    db.rename_vid()
-    db.update_metadata()
+    with stage('writer: SQLite transactions'):
+        writer.finish()
+    with stage('rename_vid + metadata'):
+        db.rename_vid()
+        db.update_metadata()
     if not args.noindex:
         os.environ['OMP_NUM_THREADS'] = str(args.cpu)
         print('Creating index...')
-        db.create_index()
+        with stage('.index'):
+            db.create_index()
     if not args.nonpz:
-        db.save_fprints(f'{args.dbfile}-dct.npz')
+        with stage('-dct.npz'):
+            db.save_fprints(f'{args.dbfile}-dct.npz')
     if not args.nodom:
-        db.save_doms(f'{args.dbfile}.dom')
+        with stage('.dom'):
+            db.save_doms(f'{args.dbfile}.dom')
+    for name, sec in STAGE_SECONDS.items():
+        logging.info(f'stage {name}: {sec:.1f} s')
     return db
 
 

@@ -51,3 +51,6 @@ def test_gpus2_on_one_gpu_over_gloo(launcher):
     assert line['config']['sequences_per_gpu'] == 2000
     assert line['parity']['mismatching_fingerprints'] == 0 and line['parity']['checked'] == 8
     assert line['value'] > 0
+    # [min, max] over the ranks: what makes a bad scaling curve diagnosable from the line alone
+    step, kern = line['per_rank_ms']['step'], line['per_rank_ms']['kernel_launch']
+    assert 0 < step[0] <= step[1] == pytest.approx(line['ms_per_step']) and 0 < kern[0] <= kern[1] <= step[1]

@@ -235,3 +235,30 @@ def test_config3_shape_ragged_batch_default_dispatch_with_goldens_inside(dd):
     doms = [[f'1-{L}'] for L in lens]
     shortest, longest = int(np.argmin(lens)), int(np.argmax(lens))
     _check_oracle(out, table, layers, offs, lens, doms, (3, 159, 162, 317, shortest, longest))
+
+
+def test_one_giant_domain_does_not_take_the_call_off_the_walk_kernel(dd):
+    """a single domain above 8 192 rows used to drop the WHOLE call to the two-kernel path.  Now
+    dctfp_quantize cuts such domains out into a call of their own; everything else still runs the walk kernel, and every
+    fingerprint lands in its own output row (the giant's fused group falls apart: parts and whole protein separately)."""
+    import torch
+    rng = np.random.default_rng(91)
+    lens = [int(v) for v in rng.integers(60, 400, size=300)]
+    lens[17] = 9000                          # a titin-sized sequence, whole-sequence domain only
+    lens[200] = 8500                         # ... and one given as two parts + the whole protein
+    doms = [[f'1-{L}'] for L in lens]
+    doms[200] = ['1-4000', '4001-8500', '1-8500']
+    doms[5] = ['1-30', '31-' + str(lens[5]), '1-' + str(lens[5])]
+    D = 640
+    layers, offs = _device_batch(torch, lens, D, 2, 777)
+    table = dd.PieceTable(lens, doms)
+    lbs = [dd.LayerBatch(x, 3, 80, row_offsets=offs) for x in layers]
+    ctx = dd.get_context(torch.cuda.current_device())
+    before = ctx.get_option('walk_launches')
+    out = dd.quantize_batch(lbs, table).cpu().numpy()
+    assert ctx.get_option('walk_launches') == before + 1      # the 300-odd ordinary domains: one walk-kernel launch
+    assert ctx.get_option('last_path') == 1                   # ... the two giants after them: two-kernel path
+    with _Options(ctx, path=1):
+        ref = dd.quantize_batch(lbs, table).cpu().numpy()
+    np.testing.assert_array_equal(out, ref)
+    _check_oracle(out, table, layers, offs, lens, doms, (5, 16, 17, 18, 200, 299))

@@ -23,4 +23,5 @@ python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.md" 2>> "$OUT/log.txt"
 # keep only the small files
 find "$OUT" -name '*.db' -delete
 find "$OUT" -name '*kernel_trace.csv' -size +2M -delete
+find "$OUT" -path '*pmc_*' -name '*kernel_trace.csv' -delete
 tail -40 "$OUT/summary.md"

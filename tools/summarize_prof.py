@@ -35,6 +35,44 @@ for f in find('trace', '*kernel_stats.csv'):
                   f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | {float(r['MaxNs']) / 1e3:.1f} | {r['Percentage']} |")
     print()
 
+# Steady state of the dominant kernel from the per-dispatch trace: `--stats` averages the first (cold: code object, page
+# faults, first touch of the tables) launch into its mean, which is what the bench line's roofline is NOT computed from --
+# bench.py times its K steps after W warm-up steps.  Drop the first WARMUP launches (profile_gpu.sh runs --warmup 1) so that
+# algorithmic bytes / this mean / 8 TB/s reproduces roofline.frac of the line printed in the same run (log.txt).
+WARMUP = int(os.environ.get('PROF_WARMUP', '1'))
+for f in find('trace', '*kernel_trace.csv'):
+    runs = []
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            name = short(r.get('Kernel_Name', ''))
+            if name in ('walk_ab_kernel', 'stage_a_kernel'):
+                runs.append((int(r['Start_Timestamp']), name, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
+    runs.sort()
+    if runs:
+        main_k = max(set(n for _, n, _ in runs), key=lambda k: sum(d for _, n, d in runs if n == k))
+        dur = [d for _, n, d in runs if n == main_k]
+        steady = dur[WARMUP:] if len(dur) > WARMUP else dur
+        mean = sum(steady) / len(steady)
+        med = sorted(steady)[len(steady) // 2]
+        print(f'## {main_k}: steady state (first {WARMUP} launch(es) = warm-up, dropped)\n')
+        print(f'- launches in order, us: {[round(d, 1) for d in dur]}')
+        print(f'- steady-state launches: {len(steady)}, mean {mean:.1f} us, median {med:.1f} us, min {min(steady):.1f} us, max {max(steady):.1f} us')
+        line = None
+        log = os.path.join(out, 'log.txt')
+        if os.path.exists(log):
+            for ln in open(log, errors='replace'):
+                if ln.startswith('{') and '"roofline"' in ln:
+                    line = json.loads(ln)
+                    break
+        if line:
+            rf = line['roofline']
+            ab = rf['algorithmic_bytes_per_launch']
+            print(f"- algorithmic bytes per launch {ab / 1e9:.4f} GB / steady-state mean = {ab / mean / 1e3:.0f} GB/s = "
+                  f"{ab / mean / 1e3 / rf['peak']:.4f} of {rf['peak']:.0f} GB/s; the bench line of the same (profiled) run: "
+                  f"avg_launch_ms {rf['avg_launch_ms']:.4f} -> frac {rf['frac']:.4f}")
+        print()
+    break
+
 counters = defaultdict(lambda: defaultdict(list))
 for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_sq2'):
     for f in find(sub, '*counter_collection.csv'):
