@@ -213,7 +213,6 @@ struct dctfp_ctx {
     uint32_t* flag_host = nullptr;             // pinned + mapped word the kernels set when they see one (option degenerate_seen)
     int n_cu = 256;  // compute units of the device (workgroup slots of the walk kernel = n_cu x workgroups per CU)
     int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0;
-    int64_t opt_ab_narrow = 0;  // walk kernel at D <= 640: 0 / 1 = five waves x 2 channels per lane, 2 = three waves x 4 (A/B)
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     int64_t walk_launches = 0;  // walk-kernel launches so far (a call split at a giant domain ends on the two-kernel path)
     int64_t test_fail_once = 0;                    // test hook: the next dctfp_quantize fails after its table lookups
@@ -566,14 +565,14 @@ struct WParams {
     hipStream_t stream;
 };
 
-template <typename T, int S, int G, int NT, int UNROLL, int VEC = 4>
+template <typename T, int S, int G, int NT, int UNROLL>
 void launch_walk_impl(const WParams& p, bool fused) {
     static const InvTab<3> inv = make_inv<3>();
     if (fused)
-        hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true, VEC>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
+        hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
                            p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
     else
-        hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, false, VEC>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
+        hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, false>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
                            p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
 }
 
@@ -592,12 +591,7 @@ int launch_walk_u(const WParams& p, int unroll, bool fused) {
 // Instantiated shapes: S waves cover up to 256 S channels; G = jobs per flush <= 4 (the rows of an MFMA tile), bounded by
 // the LDS too (2304 B per wave and job: G = 4 leaves room for 17 waves per CU, G = 3 for 23).  A flush costs the same
 // MFMAs for 1..4 jobs, so G = 4 is the default everywhere.  Half-precision rows: the default shape only.
-int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fused, int vec) {
-    if (vec == 2) {  // float32 rows at D <= 640: five waves of 128 channels, 8 bytes per lane, 16 rows in flight
-        if (dtype != DCTFP_F32 || s != 5 || g != 4) return fail(DCTFP_ERR_INVALID, "walk kernel: the 2-channel shape is float32, 5 waves, 4 jobs per flush");
-        launch_walk_impl<float, 5, 4, 5, 16, 2>(p, fused);
-        return DCTFP_OK;
-    }
+int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fused) {
     if (dtype == DCTFP_F16 || dtype == DCTFP_BF16) {
         const bool h = dtype == DCTFP_F16;
         if (s == 3) h ? launch_walk_impl<_Float16, 3, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 3, 4, 5, 8>(p, fused);
@@ -757,9 +751,6 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "ab_longest_first") {
         if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "ab_longest_first must be 0 (auto), 1 (on) or 2 (off)");
         ctx->opt_ab_longest_first = value;
-    } else if (n == "ab_narrow") {
-        if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "ab_narrow must be 0 (auto), 1 (on) or 2 (off)");
-        ctx->opt_ab_narrow = value;
     } else if (n == "ab_run_jobs") {
         if (value < 0 || value > 4096) return fail(DCTFP_ERR_INVALID, "ab_run_jobs must be 0 (auto) .. 4096");
         ctx->opt_ab_run_jobs = value;
@@ -802,7 +793,6 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     else if (n == "ab_group") *value = ctx->opt_ab_group;
     else if (n == "ab_unroll") *value = ctx->opt_ab_unroll;
     else if (n == "ab_run_jobs") *value = ctx->opt_ab_run_jobs;
-    else if (n == "ab_narrow") *value = ctx->opt_ab_narrow;
     else if (n == "ab_longest_first") *value = ctx->opt_ab_longest_first;
     else if (n == "small_b_jobs") *value = ctx->opt_small_b_jobs;
     else if (n == "degenerate_channels") {  // synchronises the device
@@ -1100,18 +1090,11 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
         const bool use_walk = walk_ok && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 256));
         // walks of ALL jobs (walk kernel) -- the two-kernel path builds its walks per chunk below
         int64_t n_walks = 0, n_runs = 0;
-        int walk_s = 0, walk_g = 0, walk_vec = 4;
+        int walk_s = 0, walk_g = 0;
         if (use_walk) {
             walk_s = g.n_cols <= 768 ? 3 : (g.n_cols <= 1280 ? 5 : 10);
             // jobs per flush: 4 = the rows of an MFMA tile (a flush costs the same MFMAs for 1..4 jobs)
             walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : 4;
-            // D <= 640 (esm2_t30, the reference's own model): three waves of 256 channels leave half of the third wave
-            // streaming padding -- a sixth of the issue slots.  Five waves of 128 channels (2 per lane, 8-byte loads of the
-            // same two 256-byte row segments per wave) are all full.
-            if (g.dtype == DCTFP_F32 && g.n_cols <= 640 && walk_g == 4 && ctx->opt_ab_narrow == 1) {
-                walk_s = 5;
-                walk_vec = 2;
-            }
             for (int64_t j = 0; j < n_jobs;) {
                 const int64_t d = j % n_domains;
                 Walk& wk = hwalk[n_walks++];
@@ -1145,7 +1128,7 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
                 const int64_t by_rows = job_rows >= 384 ? 1 : 4 * walk_g;
                 if (ctx->opt_ab_longest_first == 0) longest_first = by_rows >= walk_g && walk_s == 10;
                 // workgroups the chip holds at once (LDS: 5 / 3 / 1 per CU at 3 / 5 / 10 waves)
-                const int64_t slots = (int64_t)ctx->n_cu * (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));  // (5 waves of 2 channels: 41 KB, 3 too)
+                const int64_t slots = (int64_t)ctx->n_cu * (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));
                 if (n_jobs <= 6 * slots * by_rows) {
                     // fewer than a handful of rounds at that size: ONE round of equal workgroups instead (a second, partly
                     // filled round costs as much as a full one: 1 024 whole-protein jobs 509 us as 1 024 workgroups, 477 as 512)
@@ -1377,7 +1360,7 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             wp.degenerate = ctx->degenerate;
             wp.grid = (unsigned)n_runs;
             wp.stream = stream;
-            rc = launch_walk(wp, g.dtype, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : 8, fuse, walk_vec);
+            rc = launch_walk(wp, g.dtype, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : 8, fuse);
             if (rc) return rc;
             HIP_TRY(hipGetLastError());
             rc = prof_end(ep, stream);

@@ -23,7 +23,6 @@ namespace dctfp {
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
-typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 typedef unsigned short v4us __attribute__((ext_vector_type(4)));
@@ -130,8 +129,6 @@ template <typename T, int VEC>
 struct Raw;
 template <>
 struct Raw<float, 4> { typedef v4f type; };
-template <>
-struct Raw<float, 2> { typedef v2f type; };  // 8 bytes per lane: the walk kernel at D <= 640 (five full waves instead of 2.5 of 3)
 template <>
 struct Raw<float, 1> { typedef float type; };
 template <>
@@ -992,9 +989,6 @@ struct Run {
 #ifndef DCTFP_WALK_MIN_WAVES
 #define DCTFP_WALK_MIN_WAVES 4       // waves per SIMD the register allocation is held to (4 -> 128 VGPRs)
 #endif
-#ifndef DCTFP_WALK_ASYNC
-#define DCTFP_WALK_ASYNC 0           // 1: no workgroup barrier in a flush, the last wave to arrive finishes the rows (experiment)
-#endif
 #ifndef DCTFP_WALK_B_DEPTH
 #define DCTFP_WALK_B_DEPTH 0         // k-steps of stage-B fragments in flight during a flush: 0 = by shape (below), else 1, 2, 4
 #endif
@@ -1023,27 +1017,18 @@ struct Run {
 #define DCTFP_TL_ANCHOR(x)
 #endif
 
-template <typename T, int S, int G, int NT, int UNROLL, bool FUSED, int VEC = 4>
+template <typename T, int S, int G, int NT, int UNROLL, bool FUSED>
 __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
                                                           const Walk* __restrict__ walks, const Run* __restrict__ runs,
                                                           const PieceA* __restrict__ pieces, const double* __restrict__ stf,
                                                           int8_t* __restrict__ out, int n_cols, int64_t ld, int m,
                                                           InvTab<3> inv, unsigned long long* __restrict__ degenerate) {
-    constexpr int NK = 2;
-    static_assert(VEC == 4 || (VEC == 2 && sizeof(T) == 4), "4 channels per lane, or 2 of float32 (D <= 640)");
-    constexpr int WCH = 64 * VEC;  // channels per wave: 256 (or 128: VEC = 2)
-    // per wave and slot: WCH t values (later reused for the wave's partial 3 x (NT*16) block) + WCH state bytes
-    constexpr int SLOT = WCH > 3 * NT * 16 ? WCH : 3 * NT * 16;
-    __shared__ double lds_t[S][G][SLOT];
-    __shared__ __attribute__((aligned(4))) uint8_t lds_c[S][G][WCH];
-    // No workgroup barrier per flush: [0] counts the waves that have left their partial blocks in LDS (over all flushes so
-    // far), [1] the flushes whose cross-wave sum is done -- see "flush" below.
-    __shared__ uint32_t lds_sync[2];
-    if (threadIdx.x == 0) {
-        lds_sync[0] = 0;
-        lds_sync[1] = 0;
-    }
-    __syncthreads();  // (the only one of the kernel)
+    constexpr int VEC = 4, NK = 2;
+    constexpr int WCH = 64 * VEC;  // channels per wave
+    // per wave and slot: 256 t values (later reused for the wave's partial 3 x (NT*16) block) + 256 state bytes
+    static_assert(3 * NT * 16 <= WCH, "partial Z block must fit the slot it reuses");
+    __shared__ double lds_t[S][G][WCH];
+    __shared__ uint32_t lds_c[S][G][WCH / 4];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1052,7 +1037,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
     // images -- two 512-byte segments of every row (as fast as one of 1 KiB: tools/microbench/read_ceiling.hip) -- so that
     // the even/odd fold of the flush finds both channels of a pair in the wave's own slots.
     const int half = n_cols >> 1;
-    const int pair0 = wave * (WCH / 2) + VEC * (lane & 31);  // the first of my VEC pairs
+    const int pair0 = wave * (WCH / 2) + VEC * (lane & 31);  // the first of my 4 pairs
     const bool mirror = lane >= 32;
     const bool pad = pair0 >= half;  // out-of-range lanes stream column 0 and are discarded
     const int colc = pad ? 0 : (mirror ? n_cols - VEC - pair0 : pair0);
@@ -1061,15 +1046,12 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
     auto channel_counts = [&](int v) { return !pad && pair0 + (mirror ? VEC - 1 - v : v) < half; };
     // 16-pair groups of this wave that hold real pairs
     const int n_q = min(WCH / 32, max(0, (half + 15) / 16 - wave * (WCH / 32)));
-    typedef typename Raw<T, VEC>::type Rw;  // 4 channels per lane: 16 bytes of float32, 8 of float16 / bfloat16 (VEC = 2: 8 of float32)
+    typedef typename Raw<T, VEC>::type Rw;  // 4 channels per lane: 16 bytes of float32, 8 of float16 / bfloat16
     const int col_bytes = colc * (int)sizeof(T);       // my lane's offset inside every row
     const int ld_bytes = (int)(ld * (int64_t)sizeof(T));  // (the host sends only layers whose pieces stay below 2^31 bytes here)
 
     uint32_t pending = 0;            // jobs whose Y' sits in LDS
     uint32_t group_job = run.job_begin;  // job of slot 0
-#if DCTFP_WALK_ASYNC
-    uint32_t n_flushed = 0;          // flushes this wave has contracted
-#endif
     DCTFP_TL_DECL
 
     for (uint32_t wi = 0; wi < run.n_walks; ++wi) {
@@ -1097,6 +1079,11 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 for (int k = 0; k < NK; ++k)
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) f[k][v] = 0.0;
+                // Lanes without channels (D = 640: half of the third wave) sit the stream out with their EXEC bit off.  They
+                // used to stream column 0 and throw the result away: the same issue time either way -- but this kernel runs the
+                // chip into its power limit (the shader clock falls from 2.38 GHz on whole-protein batches to 1.9 GHz on the
+                // D = 640 database-build mix, tools/clock_probe.py), and a masked lane does not pay for 24 float64 operations per row.
+                if (!pad) {
                 {
                     const Rw r0 = load_raw<T, VEC>(reinterpret_cast<const T*>(pc[0].ptr) + colc);
 #pragma unroll
@@ -1181,6 +1168,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                         for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(dr, cwsum[k], wacc[FUSED ? k : 0][v]);
                     }
                 }
+                }  // !pad
             } else {
 #pragma unroll
                 for (int k = 0; k < NK; ++k)
@@ -1192,16 +1180,6 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
             DCTFP_TL_ANCHOR(f[0][0]);
             DCTFP_TL_ANCHOR(f[1][VEC - 1]);
             DCTFP_TL_MARK(0);
-#if DCTFP_WALK_ASYNC
-            if (pending == 0 && n_flushed > 0) {
-                // my slots still hold my partial blocks of the last flush until its cross-wave sum is done (by the wave that
-                // arrived last).  A whole job has been streamed since I arrived: this wait is over before it starts, unless
-                // another wave of the workgroup lags a whole job behind.
-                while (__hip_atomic_load(&lds_sync[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_flushed)
-                    __builtin_amdgcn_s_sleep(4);
-                DCTFP_TL_MARK(3);
-            }
-#endif
             {
                 double tv[VEC];
                 uint32_t c4 = 0;
@@ -1213,13 +1191,8 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                     c4 |= code << (8 * v);
                     __builtin_amdgcn_sched_barrier(0);  // one channel at a time (register pressure)
                 }
-                if constexpr (VEC == 4) {
-                    *reinterpret_cast<v4d*>(&lds_t[wave][pending][VEC * lane]) = (v4d){tv[0], tv[1], tv[2], tv[3]};
-                    *reinterpret_cast<uint32_t*>(&lds_c[wave][pending][VEC * lane]) = c4;
-                } else {
-                    *reinterpret_cast<v2d*>(&lds_t[wave][pending][VEC * lane]) = (v2d){tv[0], tv[1]};
-                    *reinterpret_cast<uint16_t*>(&lds_c[wave][pending][VEC * lane]) = (uint16_t)c4;
-                }
+                *reinterpret_cast<v4d*>(&lds_t[wave][pending][VEC * lane]) = (v4d){tv[0], tv[1], tv[2], tv[3]};
+                lds_c[wave][pending][lane] = c4;
             }
             ++pending;
             DCTFP_TL_MARK(1);
@@ -1277,21 +1250,19 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                     const int pl0 = 16 * qi + 4 * g4;  // my pairs of this group: pl0 + r
                     const int p0 = wave * (WCH / 2) + pl0;
                     // pairs past D/2 (D % 32 != 0) get state 0 = value 0, whatever the slots hold: byte r of the word of the
-                    // channels d, byte r ^ (VEC - 1) of the mirrors' word (a mirror lane holds its VEC channels in ascending
-                    // order: 3 - r, or r ^ 1 where D / 2 - p0 is even)
+                    // channels d, byte 3 - r of the mirrors' word
                     const int nl = min(4, max(0, half - p0));
                     const uint32_t lm = nl >= 4 ? 0xffffffffu : ((1u << (8 * nl)) - 1u);
-                    const uint32_t lmm = VEC == 2 ? lm : (nl >= 4 ? 0xffffffffu : (nl <= 0 ? 0u : ~((1u << (8 * (4 - nl))) - 1u)));
-                    const uint32_t cw = *reinterpret_cast<const uint32_t*>(&lds_c[wave][gs][pl0]) & lm;
-                    const uint32_t cwm = *reinterpret_cast<const uint32_t*>(&lds_c[wave][gs][WCH / 2 + pl0]) & lmm;
+                    const uint32_t lmm = nl >= 4 ? 0xffffffffu : (nl <= 0 ? 0u : ~((1u << (8 * (4 - nl))) - 1u));
+                    const uint32_t cw = lds_c[wave][gs][pl0 >> 2] & lm;
+                    const uint32_t cwm = lds_c[wave][gs][WCH / 8 + (pl0 >> 2)] & lmm;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        constexpr int RX = VEC - 1;  // position of pair r inside the mirror lanes' order
-                        const double t = lds_t[wave][gs][pl0 + r], tm = lds_t[wave][gs][WCH / 2 + pl0 + (r ^ RX)];
+                        const double t = lds_t[wave][gs][pl0 + r], tm = lds_t[wave][gs][WCH / 2 + pl0 + 3 - r];
 #pragma unroll
                         for (int jr = 0; jr < 3; ++jr) {
                             const double y = unpack_bits(cw, 8 * r + 2 * jr, t);
-                            const double ym = unpack_bits(cwm, 8 * (r ^ RX) + 2 * jr, tm);
+                            const double ym = unpack_bits(cwm, 8 * (3 - r) + 2 * jr, tm);
                             const double au = y + ym, av = y - ym;
                             const double ax = fma(fold_sign, ym, y);  // blocks 0, 1 of the middle column group: u, blocks 2, 3: v
                             // 3 * NT independent accumulators between two uses of one
@@ -1300,9 +1271,6 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                                 acc[jr][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(c < 2 ? au : (c == 2 ? ax : av), bq[r % DEPTH][c], acc[jr][c], 0, 0, 0);
                         }
                         fetch_b(bq[r % DEPTH], 4 * qi + r + DEPTH);
-#ifdef DCTFP_FLUSH_SCHED_BARRIER
-                        __builtin_amdgcn_sched_barrier(0);
-#endif
                     }
                 }
                 // partial blocks -> my slots (the Y' in them is consumed): tile row = lane >> 4 = job, zp[row jr][slot]
@@ -1353,30 +1321,12 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                     if (valid1) o[j * m + m - 1 - lane] = quant127(v1[j] - mn[j], den, bad);
                 }
             };
-#if DCTFP_WALK_ASYNC
-            // ---- no barrier: a wave that has left its partial blocks takes a ticket; whoever draws the last ticket of this
-            // flush finishes the rows.  Tickets are counted over all flushes: wave A cannot reach flush f + 1 before every wave
-            // has arrived at flush f, because A's next epilogue waits for the rows of flush f (above).
-            ++n_flushed;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            uint32_t ticket = 0;
-            if (lane == 0) ticket = __hip_atomic_fetch_add(&lds_sync[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
-            if (ticket + 1 == n_flushed * (uint32_t)S) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                for (uint32_t g = 0; g < pending; ++g) finish_job(g);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every block has been read: the slots are free again
-                if (lane == 0) __hip_atomic_store(&lds_sync[1], n_flushed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                DCTFP_TL_MARK(4);
-            }
-#else
             __syncthreads();
             DCTFP_TL_MARK(3);
             for (uint32_t g = (uint32_t)wave; g < pending; g += S) finish_job(g);
             DCTFP_TL_MARK(4);
             __syncthreads();  // the slots are free again
             DCTFP_TL_MARK(5);
-#endif
             group_job += pending;
             pending = 0;
         }
