@@ -165,7 +165,10 @@ __device__ inline __amdgpu_buffer_rsrc_t wave_buffer(const void* base) {  // `ba
 }
 template <typename R, bool NT>
 __device__ inline R buffer_load_raw(__amdgpu_buffer_rsrc_t rs, int lane_bytes, int uniform_bytes) {
-    constexpr int aux = NT ? 2 : 0;  // gfx94x / gfx950 cache-policy bits: 2 = nt
+#ifndef DCTFP_STREAM_AUX
+#define DCTFP_STREAM_AUX 2
+#endif
+    constexpr int aux = NT ? DCTFP_STREAM_AUX : 0;  // gfx94x / gfx950 cache-policy bits: 1 = sc0, 2 = nt, 16 = sc1
     if constexpr (sizeof(R) == 16) {
         const v4u32 r = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_bytes, uniform_bytes, aux);
         return __builtin_bit_cast(R, r);

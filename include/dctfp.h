@@ -186,12 +186,31 @@ int dctfp_host_device_pointer(void* host, void** dev);
  * dctfp_quantize writes into its pinned result buffer. */
 int dctfp_stream_synchronize(void* stream);
 
-/* Tuning / instrumentation knobs (no reference counterpart).
+/* Options (no reference counterpart).
+ *
+ * What a user of the drop-in may want:
  *   "path"         0 (default) = by shape: the walk kernel (stage A + stage B in one launch, nothing but int8 written)
  *                  for n = 3, 64 < m <= 80, float32 / float16 / bfloat16 rows, 512 <= D <= 2560 and calls of 256 jobs
- *                  (layers x domains) or more; stage A -> scratch -> stage B otherwise;
+ *                  (layers x domains) or more -- domains above 8 192 rows are cut out of such a call and run on their own;
+ *                  stage A -> scratch -> stage B otherwise.
  *                  1 = always the two-kernel path; 2 = the walk kernel wherever its shapes allow (any number of jobs)
- *   "last_path"    read only: which kernels the last dctfp_quantize launched (1 = two kernels, 2 = walk kernel)
+ *   "last_path"    read only: which kernels the last dctfp_quantize launched last (1 = two kernels, 2 = walk kernel)
+ *   "walk_launches" read only: walk-kernel launches of this context so far
+ *   "fuse"         1 (default) = proteins given as parts + whole protein are streamed once
+ *   "workspace_mb" two-kernel path: cap of the float64 scratch between the kernels
+ *   "profile"      1 = bracket the kernels with hipEvents (see dctfp_profile)
+ *   "degenerate_channels"  read: number of (layer, domain, channel) triples seen so far whose resampled values were all
+ *                  equal -- an exactly constant channel.  Mathematically that is 0/0 = NaN and the whole (layer, domain)
+ *                  block becomes 0, which is what this library writes; the reference (scipy / pocketfft) does the same at
+ *                  most domain lengths but scales its own round-off noise at the others (tests/golden/fence_golden.json:
+ *                  225 of the lengths 3..2000), so for these blocks -- and only these -- the result is reported instead of
+ *                  matched.  Reading synchronises the device; writing 0 resets the counter.
+ *   "degenerate_seen"  read: 1 if a kernel has met such a channel since the last read (then cleared).  The kernels set a
+ *                  word in pinned host memory, so this costs no synchronisation and no copy: it is meaningful once the
+ *                  caller has waited for its call.  dctdomain_amd.Fingerprint.quantize and make_db read it after every
+ *                  call / flush and log a warning with the protein ids.
+ *
+ * Engineering knobs (A/B measurements under tools/, kernel-variant parity tests; defaults are what is measured and shipped):
  *   "ab_group"     walk kernel: jobs per stage-B flush (0 = auto = 4, 3, 4)
  *   "ab_unroll"    walk kernel: rows in flight per wave (0 = 8; 4, 6, 8; float32 rows only)
  *   "ab_run_jobs"  walk kernel: jobs per workgroup (0 = by the bytes per job and the size of the call)
@@ -206,15 +225,12 @@ int dctfp_stream_synchronize(void* stream);
  *                  next sub-chunk's stage A (1 = off, default 4)
  *   "pack_y"       two-kernel path, 1 (default) = n = 3: the scratch between the kernels holds {0, t, 1} as one
  *                  float64 + 2-bit states per channel (9 bytes instead of 24)
- *   "fuse"         1 (default) = proteins given as parts + whole protein are streamed once
- *   "profile"      1 = bracket the kernels with hipEvents (see dctfp_profile)
- *   "workspace_mb" two-kernel path: cap of the float64 scratch between the kernels
- *   "degenerate_channels"  read: number of (layer, domain, channel) triples seen so far whose resampled values were all
- *                  equal -- an exactly constant channel.  Mathematically that is 0/0 = NaN and the whole (layer, domain)
- *                  block becomes 0, which is what this library writes; the reference (scipy / pocketfft) does the same at
- *                  most domain lengths but scales its own round-off noise at the others (tests/golden/fence_golden.json:
- *                  225 of the lengths 3..2000), so for these blocks -- and only these -- the result is reported instead of
- *                  matched.  Reading synchronises the device; writing 0 resets the counter. */
+ *
+ * Test hooks (tests/test_context_cache.py, tests/asan/driver.cpp):
+ *   "basis_cap_kb" size of the cosine-table arena at which it starts over (default 1 GiB); "basis_restarts" /
+ *                  "basis_tables" read how often it did / how many tables are cached
+ *   "test_fail_once" 1 = the next dctfp_quantize fails with DCTFP_ERR_NOMEM after its table lookups (nothing may stay
+ *                  cached that no kernel has filled) */
 int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value);
 int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value);
 

@@ -47,12 +47,24 @@ if [ "$MODE" = "two_resume" ]; then
     wait $PID 2>/dev/null
     T2=$(date +%s.%N)
     echo "first run ended after $(python -c "print(round($T2 - $T1, 1))") s with $(count) proteins committed; resuming"
-    python tools/run_with_rss.py $CMD --out $OUT/log2.txt > $OUT/stdout2.txt 2> $OUT/time2.txt || { tail -20 $OUT/time2.txt; exit 1; }
+    python tools/run_with_rss.py $CMD --out $OUT/log2.txt > $OUT/stdout2.txt 2> $OUT/time2.txt &
+    PID=$!
+    while kill -0 $PID 2>/dev/null; do
+        sleep 30
+        echo "  ... $(count) proteins committed (resumed run)"
+    done
+    wait $PID || { tail -20 $OUT/time2.txt; exit 1; }
     T3=$(date +%s.%N)
     echo "resumed run: $(python -c "print(round($T3 - $T2, 1))") s wall"
     grep -E "^stage " $OUT/log2.txt; grep -E "Maximum resident|Elapsed" $OUT/time2.txt
 else
-    python tools/run_with_rss.py $CMD --out $OUT/log1.txt > $OUT/stdout1.txt 2> $OUT/time1.txt || { tail -20 $OUT/time1.txt; exit 1; }
+    python tools/run_with_rss.py $CMD --out $OUT/log1.txt > $OUT/stdout1.txt 2> $OUT/time1.txt &
+    PID=$!
+    while kill -0 $PID 2>/dev/null; do       # (progress lines: a silent run of minutes is taken to be hung by the GPU pool)
+        sleep 30
+        echo "  ... $(count) proteins committed after $(python -c "import time; print(round(time.time() - $T1, 0))") s"
+    done
+    wait $PID || { tail -20 $OUT/time1.txt; exit 1; }
     T3=$(date +%s.%N)
     echo "uninterrupted run: $(python -c "print(round($T3 - $T1, 1))") s wall = $(python -c "print(round($N / ($T3 - $T1)))") proteins/s"
     grep -E "^stage " $OUT/log1.txt; grep -E "Maximum resident|Elapsed" $OUT/time1.txt
