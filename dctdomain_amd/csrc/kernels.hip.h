@@ -1221,9 +1221,14 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
             {
                 static_assert(NT == 5, "slots 0..39 = E, 40..79 = O: the middle column group is half and half");
                 static_assert(G >= 1 && G <= 4, "one MFMA row per job of the flush");
-                const int g4 = lane >> 4;
-                const int gs = min(lane & 3, G - 1);                 // my job's slot
-                const double fold_sign = (lane & 8) ? -1.0 : 1.0;  // blocks 2, 3 of the middle column group belong to O
+                // (the lane index through an opaque copy: everything the flush derives from it -- slot, masks, LDS and fragment
+                //  offsets -- would otherwise be hoisted to the top of the kernel and held in registers through the row stream,
+                //  where the fused variants have none to spare: 3 spilled registers per lane, 42 MB of scratch per launch)
+                int fl = lane;
+                asm volatile("" : "+v"(fl));
+                const int g4 = fl >> 4;
+                const int gs = min(fl & 3, G - 1);                 // my job's slot
+                const double fold_sign = (fl & 8) ? -1.0 : 1.0;  // blocks 2, 3 of the middle column group belong to O
                 double acc[3][NT];
 #pragma unroll
                 for (int jr = 0; jr < 3; ++jr)
@@ -1234,7 +1239,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 const __amdgpu_buffer_rsrc_t frag = wave_buffer(stf + (size_t)wave * (WCH / 32) * 4 * NT * 64);
                 auto fetch_b = [&](double (&b)[NT], int step) {
 #pragma unroll
-                    for (int c = 0; c < NT; ++c) b[c] = buffer_load_raw<double, false>(frag, lane * 8, (step * NT + c) * 512);
+                    for (int c = 0; c < NT; ++c) b[c] = buffer_load_raw<double, false>(frag, fl * 8, (step * NT + c) * 512);
                 };
                 // DEPTH k-steps of fragments are in flight ahead of their use: a slot is refilled for step + DEPTH right after
                 // its MFMAs.  The table ends with two groups of zeros (host: get_st), so the requests past the wave's last
@@ -1278,50 +1283,56 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 }
                 // partial blocks -> my slots (the Y' in them is consumed): tile row = lane >> 4 = job, zp[row jr][slot]
                 __builtin_amdgcn_wave_barrier();
-                if ((uint32_t)(lane >> 4) < pending) {
+                if ((uint32_t)(fl >> 4) < pending) {
 #pragma unroll
                     for (int jr = 0; jr < 3; ++jr)
 #pragma unroll
-                        for (int c = 0; c < NT; ++c) lds_t[wave][lane >> 4][jr * (NT * 16) + c * 16 + (lane & 15)] = acc[jr][c];
+                        for (int c = 0; c < NT; ++c) lds_t[wave][fl >> 4][jr * (NT * 16) + c * 16 + (fl & 15)] = acc[jr][c];
                 }
             }
             DCTFP_TL_MARK(2);
             // the three fingerprint rows of one job of the flush: sum over the waves in wave order, Z[c] = ZE[c] + ZO[c] and
             // Z[m-1-c] = ZE[c] - ZO[c], per-row min-max scale, int8 (src/fingerprint.py:193-195); lane c < ceil(m / 2) holds both.
-            // The three rows go through together: their dependent chains (S additions, the DPP reduction, two divisions)
-            // interleave, so a job costs one wave little more than a single row did.
+            // Where the registers allow, the three rows go through together: their dependent chains (S additions, the DPP
+            // reduction, two divisions) interleave, so a job costs one wave little more than a single row did.  The fused
+            // float32 variants at the 128-register budget take them one by one (together they spill 4 registers per lane).
+            constexpr int ROWS = (FUSED && S < 10 && sizeof(T) == 4) ? 1 : 3;
             auto finish_job = [&](uint32_t g) {
                 const int hm = (m + 1) >> 1;
                 const bool valid0 = lane < hm;
                 const bool valid1 = lane < hm && (m - 1 - lane) != lane;  // odd m: the middle column is its own mirror (O = 0 there)
-                double v0[3], v1[3], mn[3], mx[3];
-                bool nan_here[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    double ze = 0.0, zo = 0.0;
-                    if (valid0) {
-#pragma unroll
-                        for (int w = 0; w < S; ++w) {
-                            ze += lds_t[w][g][j * (NT * 16) + lane];
-                            zo += lds_t[w][g][j * (NT * 16) + 40 + lane];
-                        }
-                    }
-                    v0[j] = ze + zo;
-                    v1[j] = ze - zo;
-                    mn[j] = valid0 ? fmin(v0[j], valid1 ? v1[j] : v0[j]) : INFINITY;
-                    mx[j] = valid0 ? fmax(v0[j], valid1 ? v1[j] : v0[j]) : -INFINITY;
-                    nan_here[j] = valid0 && (v0[j] != v0[j] || v1[j] != v1[j]);
-                }
-                static_assert(DCTFP_MAX_M_K <= 128 && NT * 16 <= 80, "lanes 0 .. 39 hold a row");
-#pragma unroll
-                for (int j = 0; j < 3; ++j) wave_min_max48(mn[j], mx[j]);
                 int8_t* __restrict__ o = out + jobb[group_job + g].out_off;
+                static_assert(DCTFP_MAX_M_K <= 128 && NT * 16 <= 80, "lanes 0 .. 39 hold a row");
+                for (int j0 = 0; j0 < 3; j0 += ROWS) {
+                    double v0[ROWS], v1[ROWS], mn[ROWS], mx[ROWS];
+                    bool nan_here[ROWS];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const bool bad = __builtin_amdgcn_ballot_w64(nan_here[j]) != 0;  // a NaN anywhere in the row: the whole row is 0
-                    const double den = mx[j] - mn[j];
-                    if (valid0) o[j * m + lane] = quant127(v0[j] - mn[j], den, bad);
-                    if (valid1) o[j * m + m - 1 - lane] = quant127(v1[j] - mn[j], den, bad);
+                    for (int jj = 0; jj < ROWS; ++jj) {
+                        const int j = j0 + jj;
+                        double ze = 0.0, zo = 0.0;
+                        if (valid0) {
+#pragma unroll
+                            for (int w = 0; w < S; ++w) {
+                                ze += lds_t[w][g][j * (NT * 16) + lane];
+                                zo += lds_t[w][g][j * (NT * 16) + 40 + lane];
+                            }
+                        }
+                        v0[jj] = ze + zo;
+                        v1[jj] = ze - zo;
+                        mn[jj] = valid0 ? fmin(v0[jj], valid1 ? v1[jj] : v0[jj]) : INFINITY;
+                        mx[jj] = valid0 ? fmax(v0[jj], valid1 ? v1[jj] : v0[jj]) : -INFINITY;
+                        nan_here[jj] = valid0 && (v0[jj] != v0[jj] || v1[jj] != v1[jj]);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < ROWS; ++jj) wave_min_max48(mn[jj], mx[jj]);
+#pragma unroll
+                    for (int jj = 0; jj < ROWS; ++jj) {
+                        const int j = j0 + jj;
+                        const bool bad = __builtin_amdgcn_ballot_w64(nan_here[jj]) != 0;  // a NaN anywhere in the row: the whole row is 0
+                        const double den = mx[jj] - mn[jj];
+                        if (valid0) o[j * m + lane] = quant127(v0[jj] - mn[jj], den, bad);
+                        if (valid1) o[j * m + m - 1 - lane] = quant127(v1[jj] - mn[jj], den, bad);
+                    }
                 }
             };
             __syncthreads();

@@ -11,7 +11,9 @@ export TMPDIR=/tmp
 cd /tmp
 BENCH="python3 $REPO/bench.py --cpu-seconds 0 --parity-sample 0 $*"
 echo "== kernel trace + stats" | tee "$OUT/log.txt"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps 5 --warmup 1 >> "$OUT/log.txt" 2>&1 || exit 1
+# (the bench's own step count and warm-up: what `--stats` and the steady-state summary see is then the line's timed region)
+export PROF_WARMUP=3
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH --steps 20 --warmup 3 >> "$OUT/log.txt" 2>&1 || exit 1
 echo "== pmc FETCH_SIZE" | tee -a "$OUT/log.txt"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps 2 --warmup 1 >> "$OUT/log.txt" 2>&1 || exit 1
 echo "== pmc WRITE_SIZE" | tee -a "$OUT/log.txt"
