@@ -30,22 +30,40 @@ def _stale(target: str, sources) -> bool:
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> dctdomain_amd/libdctfp.so.  Returns the path."""
+EXPERIMENTS_LIB_PATH = os.path.join(PKG_DIR, 'libdctfp_experiments.so')
+
+
+def _library_commands(force: bool):
+    """[(target, command)] of what has to be (re)built: the product library and its twin with the engineering knobs and
+    test hooks compiled in (-DDCTFP_EXPERIMENTS: dctfp_set_option names that tools/ and the kernel-variant / cache tests use;
+    same kernels, same dispatch)."""
     sources = [os.path.join(CSRC, 'dctfp.hip'), os.path.join(CSRC, 'kernels.hip.h'),
                os.path.join(ROOT, 'include', 'dctfp.h')]
-    if force or _stale(LIB_PATH, sources):
-        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-               '-I', os.path.join(ROOT, 'include'), '-o', LIB_PATH, sources[0]]
+    base = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-I', os.path.join(ROOT, 'include')]
+    out = []
+    for target, extra in ((LIB_PATH, []), (EXPERIMENTS_LIB_PATH, ['-DDCTFP_EXPERIMENTS'])):
+        if force or _stale(target, sources):
+            out.append((target, base + extra + ['-o', target, sources[0]]))
+    return out
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> dctdomain_amd/libdctfp.so (+ libdctfp_experiments.so), the two compilations side by
+    side.  Returns the path of the product library."""
+    procs = []
+    for target, cmd in _library_commands(force):
         if verbose:
             print(' '.join(cmd))
-        subprocess.run(cmd, check=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, proc in procs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
     return LIB_PATH
 
 
 def build_all(force: bool = False, verbose: bool = False):
     """Every native piece of the product (HIP kernels + host-side C++ helpers)."""
-    paths = [build_library(force=force, verbose=verbose)]
+    paths = [build_library(force=force, verbose=verbose), EXPERIMENTS_LIB_PATH]
     reccut_src = os.path.join(CSRC, 'reccut.cpp')
     if os.path.exists(reccut_src):
         if force or _stale(RECCUT_LIB_PATH, [reccut_src, os.path.join(ROOT, 'include', 'reccut.h')]):

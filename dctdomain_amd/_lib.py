@@ -11,6 +11,9 @@ import numpy as np
 
 LIB_PATH = os.environ.get('DCTFP_LIBRARY') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdctfp.so')
 RECCUT_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libreccut.so')
+#: the same library with the engineering knobs and test hooks of dctfp_set_option compiled in (-DDCTFP_EXPERIMENTS): what
+#: tools/ and the kernel-variant / cache tests load; the product (`LIB_PATH`) knows only the options of include/dctfp.h
+EXPERIMENTS_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdctfp_experiments.so')
 
 DCTFP_OK = 0
 DCTFP_ERR_INVALID = -1
@@ -179,6 +182,23 @@ def get_context(device: int) -> Context:
         if ctx is None:
             ctx = Context(device)
             _contexts[key] = ctx
+        return ctx
+
+
+_experiment_contexts = {}
+
+
+def experiments_context(device: int) -> Context:
+    """A context of libdctfp_experiments.so (one per process and device) -- for tests and tools only."""
+    with _ctx_lock:
+        key = (os.getpid(), int(device))
+        ctx = _experiment_contexts.get(key)
+        if ctx is None:
+            if not os.path.exists(EXPERIMENTS_LIB_PATH):
+                raise ImportError(f'{EXPERIMENTS_LIB_PATH} is missing: run python build_ext.py')
+            import torch  # noqa: F401  (before the library: see load())
+            ctx = Context(device, load(EXPERIMENTS_LIB_PATH))
+            _experiment_contexts[key] = ctx
         return ctx
 
 

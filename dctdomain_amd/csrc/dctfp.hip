@@ -719,7 +719,27 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(DCTFP_ERR_INVALID, "dctfp_set_option: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     std::string n(name);
-    if (n == "stage_b") {
+    // ---- what a user of the library sets (include/dctfp.h)
+    if (n == "path") {
+        if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "path must be 0 (auto), 1 (stage A -> Y' -> stage B) or 2 (walk kernel wherever its shapes allow)");
+        ctx->opt_path = value;
+    } else if (n == "fuse") {
+        ctx->opt_fuse = value ? 1 : 0;
+    } else if (n == "workspace_mb") {
+        if (value < 16) return fail(DCTFP_ERR_INVALID, "workspace_mb must be >= 16");
+        ctx->opt_ws_mb = value;
+    } else if (n == "profile") {
+        ctx->opt_profile = value ? 1 : 0;
+    } else if (n == "degenerate_channels") {
+        if (value != 0) return fail(DCTFP_ERR_INVALID, "degenerate_channels can only be reset to 0");
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemset(ctx->degenerate, 0, kFlagSlot * sizeof(unsigned long long)));  // (slot 15 keeps the flag's address)
+        *ctx->flag_host = 0;
+    }
+#ifdef DCTFP_EXPERIMENTS
+    // ---- engineering knobs and test hooks: libdctfp_experiments.so only (A/B tools, kernel-variant parity tests, cache tests)
+    else if (n == "stage_b") {
         if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "stage_b must be 0 or 1");
         ctx->opt_stage_b = value;
     } else if (n == "a_waves") {
@@ -731,19 +751,12 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         ctx->opt_a_unroll = value;
     } else if (n == "pack_y") {
         ctx->opt_pack_y = value ? 1 : 0;
-    } else if (n == "fuse") {
-        ctx->opt_fuse = value ? 1 : 0;
-    } else if (n == "path") {
-        if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "path must be 0 (auto), 1 (stage A -> Y' -> stage B) or 2 (walk kernel wherever its shapes allow)");
-        ctx->opt_path = value;
     } else if (n == "ab_group") {
         if (value != 0 && value != 3 && value != 4) return fail(DCTFP_ERR_INVALID, "ab_group must be 0 (auto), 3 or 4 jobs per flush");
         ctx->opt_ab_group = value;
     } else if (n == "ab_unroll") {
-#ifdef DCTFP_EXPERIMENTS
-        if (value == 12 || value == 16) { ctx->opt_ab_unroll = value; return DCTFP_OK; }
-#endif
-        if (value != 0 && value != 4 && value != 6 && value != 8) return fail(DCTFP_ERR_INVALID, "ab_unroll must be 0 (auto), 4, 6 or 8");
+        if (value != 0 && value != 4 && value != 6 && value != 8 && value != 12 && value != 16)
+            return fail(DCTFP_ERR_INVALID, "ab_unroll must be 0 (auto), 4, 6, 8 (12, 16: D > 1280 only)");
         ctx->opt_ab_unroll = value;
     } else if (n == "small_b_jobs") {
         if (value < 0 || value > 1 << 20) return fail(DCTFP_ERR_INVALID, "small_b_jobs must be 0 .. 2^20");
@@ -754,26 +767,17 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "ab_run_jobs") {
         if (value < 0 || value > 4096) return fail(DCTFP_ERR_INVALID, "ab_run_jobs must be 0 (auto) .. 4096");
         ctx->opt_ab_run_jobs = value;
-    } else if (n == "degenerate_channels") {
-        if (value != 0) return fail(DCTFP_ERR_INVALID, "degenerate_channels can only be reset to 0");
-        HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemset(ctx->degenerate, 0, kFlagSlot * sizeof(unsigned long long)));  // (slot 15 keeps the flag's address)
-        *ctx->flag_host = 0;
+    } else if (n == "overlap") {
+        if (value < 1 || value > kMaxSlots) return fail(DCTFP_ERR_INVALID, "overlap must be 1..%d", kMaxSlots);
+        ctx->opt_overlap = value;
     } else if (n == "test_fail_once") {
         ctx->test_fail_once = value ? 1 : 0;
     } else if (n == "basis_cap_kb") {
         if (value < 1) return fail(DCTFP_ERR_INVALID, "basis_cap_kb must be >= 1");
         ctx->basis_cap_doubles = value * 128;
-    } else if (n == "overlap") {
-        if (value < 1 || value > kMaxSlots) return fail(DCTFP_ERR_INVALID, "overlap must be 1..%d", kMaxSlots);
-        ctx->opt_overlap = value;
-    } else if (n == "profile") {
-        ctx->opt_profile = value ? 1 : 0;
-    } else if (n == "workspace_mb") {
-        if (value < 16) return fail(DCTFP_ERR_INVALID, "workspace_mb must be >= 16");
-        ctx->opt_ws_mb = value;
-    } else {
+    }
+#endif
+    else {
         return fail(DCTFP_ERR_INVALID, "unknown option '%s'", name);
     }
     return DCTFP_OK;
@@ -783,25 +787,37 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     if (!ctx || !name || !value) return fail(DCTFP_ERR_INVALID, "dctfp_get_option: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     std::string n(name);
-    if (n == "stage_b") *value = ctx->opt_stage_b;
-    else if (n == "a_waves") *value = ctx->opt_a_waves;
-    else if (n == "a_unroll") *value = ctx->opt_a_unroll;
-    else if (n == "overlap") *value = ctx->opt_overlap;
-    else if (n == "path") *value = ctx->opt_path;
+    if (n == "path") *value = ctx->opt_path;
     else if (n == "last_path") *value = ctx->last_path;
     else if (n == "walk_launches") *value = ctx->walk_launches;
-    else if (n == "ab_group") *value = ctx->opt_ab_group;
-    else if (n == "ab_unroll") *value = ctx->opt_ab_unroll;
-    else if (n == "ab_run_jobs") *value = ctx->opt_ab_run_jobs;
-    else if (n == "ab_longest_first") *value = ctx->opt_ab_longest_first;
-    else if (n == "small_b_jobs") *value = ctx->opt_small_b_jobs;
+    else if (n == "fuse") *value = ctx->opt_fuse;
+    else if (n == "workspace_mb") *value = ctx->opt_ws_mb;
+    else if (n == "profile") *value = ctx->opt_profile;
     else if (n == "degenerate_channels") {  // synchronises the device
         unsigned long long v = 0;
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(&v, ctx->degenerate, sizeof v, hipMemcpyDeviceToHost));
         *value = (int64_t)v;
+    } else if (n == "degenerate_seen") {  // no device synchronisation: meaningful once the caller has waited for its call
+        *value = *(volatile uint32_t*)ctx->flag_host ? 1 : 0;
+        *(volatile uint32_t*)ctx->flag_host = 0;
     }
+#ifdef DCTFP_EXPERIMENTS
+    else if (n == "stage_b") *value = ctx->opt_stage_b;
+    else if (n == "a_waves") *value = ctx->opt_a_waves;
+    else if (n == "a_unroll") *value = ctx->opt_a_unroll;
+    else if (n == "overlap") *value = ctx->opt_overlap;
+    else if (n == "ab_group") *value = ctx->opt_ab_group;
+    else if (n == "ab_unroll") *value = ctx->opt_ab_unroll;
+    else if (n == "ab_run_jobs") *value = ctx->opt_ab_run_jobs;
+    else if (n == "ab_longest_first") *value = ctx->opt_ab_longest_first;
+    else if (n == "small_b_jobs") *value = ctx->opt_small_b_jobs;
+    else if (n == "pack_y") *value = ctx->opt_pack_y;
+    else if (n == "basis_cap_kb") *value = ctx->basis_cap_doubles / 128;
+    else if (n == "basis_restarts") *value = ctx->basis_restarts;
+    else if (n == "basis_tables") *value = (int64_t)ctx->basis_tabs.size();
+#endif
 #ifdef DCTFP_WALK_TIMELINE
     else if (n.rfind("walk_timeline_", 0) == 0) {  // instrumented build: cycles per phase (kernels.hip.h), synchronises the device
         const int i = atoi(n.c_str() + 14);
@@ -813,17 +829,6 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
         *value = (int64_t)v;
     }
 #endif
-    else if (n == "degenerate_seen") {  // no device synchronisation: meaningful once the caller has waited for its call
-        *value = *(volatile uint32_t*)ctx->flag_host ? 1 : 0;
-        *(volatile uint32_t*)ctx->flag_host = 0;
-    }
-    else if (n == "fuse") *value = ctx->opt_fuse;
-    else if (n == "basis_cap_kb") *value = ctx->basis_cap_doubles / 128;
-    else if (n == "basis_restarts") *value = ctx->basis_restarts;
-    else if (n == "basis_tables") *value = (int64_t)ctx->basis_tabs.size();
-    else if (n == "pack_y") *value = ctx->opt_pack_y;
-    else if (n == "profile") *value = ctx->opt_profile;
-    else if (n == "workspace_mb") *value = ctx->opt_ws_mb;
     else return fail(DCTFP_ERR_INVALID, "unknown option '%s'", name);
     return DCTFP_OK;
 }
@@ -1308,10 +1313,12 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
         if (rc) return rc;
         const int ldy = st->ldy;
 
+#ifdef DCTFP_EXPERIMENTS
         if (ctx->test_fail_once) {  // test hook: an allocation failure between the table lookup and the fill kernel
             ctx->test_fail_once = 0;
             return fail(DCTFP_ERR_NOMEM, "injected failure (option test_fail_once)");
         }
+#endif
         if (!fresh.empty()) {  // cosine tables this context has not seen yet (grid.y is limited to 65535)
             // tables cached by earlier calls may have been filled on another stream: chain the events, so that whoever
             // waits for the new ev_basis also has the older fills behind it

@@ -210,7 +210,9 @@ int dctfp_stream_synchronize(void* stream);
  *                  caller has waited for its call.  dctdomain_amd.Fingerprint.quantize and make_db read it after every
  *                  call / flush and log a warning with the protein ids.
  *
- * Engineering knobs (A/B measurements under tools/, kernel-variant parity tests; defaults are what is measured and shipped):
+ * Engineering knobs -- ONLY in libdctfp_experiments.so, the same sources built with -DDCTFP_EXPERIMENTS (A/B measurements
+ * under tools/, kernel-variant parity tests); libdctfp.so answers DCTFP_ERR_INVALID "unknown option" to them.  Their
+ * defaults are what is measured and shipped:
  *   "ab_group"     walk kernel: jobs per stage-B flush (0 = auto = 4, 3, 4)
  *   "ab_unroll"    walk kernel: rows in flight per wave (0 = 8; 4, 6, 8; float32 rows only)
  *   "ab_run_jobs"  walk kernel: jobs per workgroup (0 = by the bytes per job and the size of the call)
@@ -226,7 +228,7 @@ int dctfp_stream_synchronize(void* stream);
  *   "pack_y"       two-kernel path, 1 (default) = n = 3: the scratch between the kernels holds {0, t, 1} as one
  *                  float64 + 2-bit states per channel (9 bytes instead of 24)
  *
- * Test hooks (tests/test_context_cache.py, tests/asan/driver.cpp):
+ * Test hooks (libdctfp_experiments.so only; tests/test_context_cache.py, tests/asan/driver.cpp):
  *   "basis_cap_kb" size of the cosine-table arena at which it starts over (default 1 GiB); "basis_restarts" /
  *                  "basis_tables" read how often it did / how many tables are cached
  *   "test_fail_once" 1 = the next dctfp_quantize fails with DCTFP_ERR_NOMEM after its table lookups (nothing may stay

@@ -15,7 +15,8 @@ def _ensure_native_built():
     (hipcc cross-compiles without a GPU).  The CPU checkers of oracle/ are built the same way."""
     import subprocess
     import build_ext
-    if not (os.path.exists(build_ext.LIB_PATH) and os.path.exists(build_ext.RECCUT_LIB_PATH)):
+    if not (os.path.exists(build_ext.LIB_PATH) and os.path.exists(build_ext.RECCUT_LIB_PATH)
+            and os.path.exists(build_ext.EXPERIMENTS_LIB_PATH)):
         build_ext.build_all()
     if not os.path.exists(os.path.join(ROOT, 'oracle', '_build', 'liboracle.so')):
         subprocess.run(['make', '-C', os.path.join(ROOT, 'oracle'), 'all'], check=True)

@@ -11,6 +11,12 @@ from recipes import make_input
 pytestmark = pytest.mark.gpu
 
 
+def _xctx(torch):
+    """The test hooks (test_fail_once, basis_cap_kb, basis_*) exist in libdctfp_experiments.so only."""
+    from dctdomain_amd import _lib
+    return _lib.experiments_context(torch.cuda.current_device())
+
+
 def _batch(dd, torch, lens, seed, D=640):
     xs = [make_input('esm', L, D, seed + i) for i, L in enumerate(lens)]
     table = dd.PieceTable.whole_sequences(lens)
@@ -27,18 +33,18 @@ def test_failed_call_leaves_no_unfilled_table_in_the_cache():
     kernel had filled -- every later call with those lengths returned wrong fingerprints with rc == OK."""
     import torch
     import dctdomain_amd as dd
-    ctx = dd.get_context(torch.cuda.current_device())
+    ctx = _xctx(torch)
     lens = [1777, 1778, 1779, 91]                 # lengths no other test uses: fresh tables for this context
     xs, table, lb = _batch(dd, torch, lens, 4100)
     before = ctx.get_option('basis_tables')
     ctx.set_option('test_fail_once', 1)
     with pytest.raises(MemoryError, match='injected failure'):
-        dd.quantize_batch([lb], table)
+        dd.quantize_batch([lb], table, ctx=ctx)
     assert ctx.get_option('basis_tables') == before            # nothing published
-    out = dd.quantize_batch([lb], table).cpu().numpy()         # the retry fills and publishes them
+    out = dd.quantize_batch([lb], table, ctx=ctx).cpu().numpy()         # the retry fills and publishes them
     assert ctx.get_option('basis_tables') >= before + 3
     np.testing.assert_array_equal(out.astype(np.int64), _expect(xs, lens))
-    out2 = dd.quantize_batch([lb], table).cpu().numpy()        # ... and a call served from the cache agrees
+    out2 = dd.quantize_batch([lb], table, ctx=ctx).cpu().numpy()        # ... and a call served from the cache agrees
     np.testing.assert_array_equal(out2, out)
 
 
@@ -48,7 +54,7 @@ def test_arena_restart_with_a_call_in_flight_on_another_stream():
     first is in flight; both results must be right and the restart counted."""
     import torch
     import dctdomain_amd as dd
-    ctx = dd.get_context(torch.cuda.current_device())
+    ctx = _xctx(torch)
     lens_a = [1500 + 3 * i for i in range(300)]                 # 300 tables, ~48 KB each: far above the cap
     lens_b = [1201 + 2 * i for i in range(40)]
     xa, ta, la = _batch(dd, torch, lens_a, 5200)
@@ -59,9 +65,9 @@ def test_arena_restart_with_a_call_in_flight_on_another_stream():
     torch.cuda.synchronize()
     try:
         ctx.set_option('basis_cap_kb', 64)
-        out_a = dd.quantize_batch([la], ta, stream=sa)          # fills ~14 MB of tables: over the cap from now on
-        out_b = dd.quantize_batch([lb], tb, stream=sb)          # -> purge (waits for stream A), fresh tables, other stream
-        out_a2 = dd.quantize_batch([la], ta, stream=sa)         # -> purge again, call B possibly still in flight
+        out_a = dd.quantize_batch([la], ta, stream=sa, ctx=ctx)          # fills ~14 MB of tables: over the cap from now on
+        out_b = dd.quantize_batch([lb], tb, stream=sb, ctx=ctx)          # -> purge (waits for stream A), fresh tables, other stream
+        out_a2 = dd.quantize_batch([la], ta, stream=sa, ctx=ctx)         # -> purge again, call B possibly still in flight
         torch.cuda.synchronize()
     finally:
         ctx.set_option('basis_cap_kb', old_cap)
@@ -72,7 +78,7 @@ def test_arena_restart_with_a_call_in_flight_on_another_stream():
     pick = [0, 20, 39]
     np.testing.assert_array_equal(out_b.cpu().numpy()[pick].astype(np.int64), _expect([xb[i] for i in pick], [lens_b[i] for i in pick]))
     # and the context is healthy afterwards, cache refilled under the normal cap
-    out_b2 = dd.quantize_batch([lb], tb).cpu().numpy()
+    out_b2 = dd.quantize_batch([lb], tb, ctx=ctx).cpu().numpy()
     np.testing.assert_array_equal(out_b2, out_b.cpu().numpy())
 
 
@@ -89,7 +95,7 @@ def test_cached_tables_filled_on_one_stream_are_ordered_for_another():
     lb = dd.LayerBatch([torch.from_numpy(x).cuda() for x in xb], 3, 80)
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
-    out_a = dd.quantize_batch([la], ta, stream=sa)
+    out_a = dd.quantize_batch([la], ta, stream=sa)            # (the product library: no hook needed here)
     out_b = dd.quantize_batch([lb], tb, stream=sb)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out_b.cpu().numpy()[:32], out_a.cpu().numpy()[:32])

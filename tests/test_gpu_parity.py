@@ -73,22 +73,30 @@ def walk_eligible(case, layers):
                          ids=['valuB', 'mfmaB', 'w8u4', 'w16u8', 'w4u4', 'smallws', 'w2u8', 'w1', 'nooverlap', 'nofuse', 'nopack',
                               'twokernels', 'twokernels_nofuse', 'walk_u4', 'walk_u6', 'walk_u8', 'walk_g3', 'walk_g4', 'walk_forced', 'walk_run4', 'walk_run64', 'walk_run1', 'mfmaB_small_calls', 'slabB_always'])
 def test_kernel_variants_agree_with_golden(dd, opts):
+    """Every kernel configuration the dispatch can pick (and the engineering knobs can force) against the golden subset.
+    The knobs live in libdctfp_experiments.so only (same kernels and dispatch as the product, -DDCTFP_EXPERIMENTS), so this
+    test drives that library through the batch API."""
     import torch
-    ctx = dd.get_context(torch.cuda.current_device())
+    from dctdomain_amd import _lib
+    ctx = _lib.experiments_context(torch.cuda.current_device())
     saved = {k: ctx.get_option(k) for k in opts}
     try:
         for k, v in opts.items():
             ctx.set_option(k, v)
         for case in SUBSET:
             layers = gu.build_layers(case)
-            fp = run_fp(dd, layers, case['domains'], case['qdim'], as_tensor=True)
+            qd = case['qdim']
+            assert all(x.shape[0] == layers[0].shape[0] for x in layers)
+            table = dd.PieceTable([layers[0].shape[0]], [case['domains']])
+            assert table.keys == case['keys']
+            lbs = [dd.LayerBatch([torch.from_numpy(x).cuda()], qd[2 * i], qd[2 * i + 1]) for i, x in enumerate(layers)]
+            out = dd.quantize_batch(lbs, table, ctx=ctx).cpu().numpy()
             if opts.get('path') == 2 and walk_eligible(case, layers):
                 # a one-protein call reaches the walk kernel only when it is forced: make sure it did
                 assert ctx.get_option('last_path') == 2, f"{case['id']} did not run walk_ab_kernel under {opts}"
             exp = gu.expected(case)
-            assert list(fp.quants.keys()) == case['keys']
-            for k in exp:
-                np.testing.assert_array_equal(fp.quants[k], exp[k].astype(np.int64), err_msg=f"{case['id']} {k} {opts}")
+            for row, key in enumerate(case['keys']):
+                np.testing.assert_array_equal(out[row].astype(np.int64), exp[key].astype(np.int64), err_msg=f"{case['id']} {key} {opts}")
     finally:
         for k, v in saved.items():
             ctx.set_option(k, v)
@@ -686,18 +694,21 @@ def test_midsize_calls_fused_walks_with_both_stage_b_forms(dd):
     table = dd.PieceTable(lens, doms)
     assert 64 <= 2 * table.n_domains < 256
     lbs = [dd.LayerBatch([torch.from_numpy(x[li]).cuda() for x in xs], 3, 80) for li in range(2)]
-    saved = {k: ctx.get_option(k) for k in ('small_b_jobs', 'fuse')}
+    from dctdomain_amd import _lib
+    xctx = _lib.experiments_context(torch.cuda.current_device())      # (the slab / MFMA stage-B switch is an engineering knob)
+    saved = {k: xctx.get_option(k) for k in ('small_b_jobs', 'fuse')}
     try:
         out = dd.quantize_batch(lbs, table).cpu().numpy()
         assert ctx.get_option('last_path') == 1
-        ctx.set_option('small_b_jobs', 0)
-        assert (dd.quantize_batch(lbs, table).cpu().numpy() == out).all()
-        ctx.set_option('small_b_jobs', saved['small_b_jobs'])
-        ctx.set_option('fuse', 0)
-        assert (dd.quantize_batch(lbs, table).cpu().numpy() == out).all()
+        assert (dd.quantize_batch(lbs, table, ctx=xctx).cpu().numpy() == out).all()
+        xctx.set_option('small_b_jobs', 0)
+        assert (dd.quantize_batch(lbs, table, ctx=xctx).cpu().numpy() == out).all()
+        xctx.set_option('small_b_jobs', saved['small_b_jobs'])
+        xctx.set_option('fuse', 0)
+        assert (dd.quantize_batch(lbs, table, ctx=xctx).cpu().numpy() == out).all()
     finally:
         for k, v in saved.items():
-            ctx.set_option(k, v)
+            xctx.set_option(k, v)
     row = 0
     for s in range(44):
         for dom in doms[s]:

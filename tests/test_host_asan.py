@@ -50,7 +50,7 @@ def test_host_code_under_address_sanitizer(tmp_path):
     flags = ['-O1', '-g', '-std=c++17', '-fsanitize=address', '-fno-omit-frame-pointer']
     inc = ['-I', os.path.join(ROOT, 'include'), '-I', os.path.join(ROOT, 'dctdomain_amd', 'csrc')]
     host_o, stub_o, syms, exe = (str(tmp_path / n) for n in ('dctfp_host.o', 'hip_stub.o', 'fatbin_syms.cpp', 'driver'))
-    subprocess.run([HIPCC, '--offload-arch=gfx950', '--cuda-host-only', '-fPIC', *flags, *inc, '-c',
+    subprocess.run([HIPCC, '--offload-arch=gfx950', '--cuda-host-only', '-fPIC', '-DDCTFP_EXPERIMENTS', *flags, *inc, '-c',
                     os.path.join(ROOT, 'dctdomain_amd', 'csrc', 'dctfp.hip'), '-o', host_o], check=True)
     subprocess.run([CLANG, '-D__HIP_PLATFORM_AMD__', '-fPIC', *flags, '-I', '/opt/rocm/include', '-c',
                     os.path.join(ROOT, 'tests', 'asan', 'hip_stub.cpp'), '-o', stub_o], check=True)

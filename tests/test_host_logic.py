@@ -21,11 +21,12 @@ def test_library_exports_every_declared_symbol():
         header = fh.read()
     declared = sorted(set(re.findall(r'\b(dctfp_[a-z0-9_]+)\s*\(', header)))
     assert len(declared) >= 11
-    lib = ctypes.CDLL(_lib.LIB_PATH)
-    for name in declared:
-        assert hasattr(lib, name), f'{name} declared in include/dctfp.h but not exported'
+    for path in (_lib.LIB_PATH, _lib.EXPERIMENTS_LIB_PATH):      # the product and its twin with the engineering knobs
+        lib = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(lib, name), f'{name} declared in include/dctfp.h but not exported by {path}'
+        assert lib.dctfp_version() == int(re.search(r'#define DCTFP_VERSION (\d+)', header).group(1))
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.dctfp_version() == int(re.search(r'#define DCTFP_VERSION (\d+)', header).group(1))
 
 
 def test_struct_layouts_match_header():

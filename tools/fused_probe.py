@@ -2,6 +2,7 @@
 different domain lists: isolates the cost of the fused variant from the cost of short parts."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._experiments  # noqa: F401  (engineering knobs: libdctfp_experiments.so unless DCTFP_LIBRARY says otherwise)
 import numpy as np, torch
 import dctdomain_amd as dd
 dev = torch.device('cuda', 0)

@@ -1,5 +1,6 @@
 import os, sys, time
 sys.path.insert(0, '/root/repo')
+import tools._experiments  # noqa: F401  (engineering knobs: libdctfp_experiments.so unless DCTFP_LIBRARY says otherwise)
 import numpy as np, torch
 import dctdomain_amd as dd
 dev = torch.device('cuda', 0)

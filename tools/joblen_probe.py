@@ -3,6 +3,7 @@
 short jobs from everything else (same bytes, same allocation for every case)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._experiments  # noqa: F401  (engineering knobs: libdctfp_experiments.so unless DCTFP_LIBRARY says otherwise)
 import numpy as np, torch
 import dctdomain_amd as dd
 dev = torch.device('cuda', 0)

@@ -3,6 +3,7 @@ Two-kernel path (option path = 1): does stage B really run under stage A?  Same 
 domain lists with a growing number of fingerprints per byte; sweeps the stage-A launch shape and the overlap depth."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._experiments  # noqa: F401  (engineering knobs: libdctfp_experiments.so unless DCTFP_LIBRARY says otherwise)
 import numpy as np, torch
 import dctdomain_amd as dd
 dev = torch.device('cuda', 0)

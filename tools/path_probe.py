@@ -4,6 +4,7 @@ workload, configurations interleaved (ABAB) so that allocation-to-allocation spr
 usage: python tools/path_probe.py [c2 c3 c4 c5 ...] [--cfg name=value,name=value ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._experiments  # noqa: F401  (engineering knobs: libdctfp_experiments.so unless DCTFP_LIBRARY says otherwise)
 import numpy as np, torch
 import dctdomain_amd as dd
 import bench

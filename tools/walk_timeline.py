@@ -8,6 +8,7 @@ Every wave adds the shader-clock cycles between its phase marks to device counte
 the table is the share of the summed wave lifetimes, plus cycles per job / per flush."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._experiments  # noqa: F401  (engineering knobs: libdctfp_experiments.so unless DCTFP_LIBRARY says otherwise)
 import numpy as np, torch
 import dctdomain_amd as dd
 import bench
