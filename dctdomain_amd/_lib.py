@@ -115,11 +115,12 @@ def _configure(lib):
         return lib
 
 
-def check(rc: int):
-    """Maps a return code to the exception the reference would raise."""
+def check(rc: int, lib=None):
+    """Maps a return code to the exception the reference would raise.  ``lib``: the library the call went to (its last
+    error message is per library and thread); default: the product library."""
     if rc == DCTFP_OK:
         return
-    msg = load().dctfp_last_error().decode('utf-8', 'replace')
+    msg = (lib if lib is not None else load()).dctfp_last_error().decode('utf-8', 'replace')
     if rc == DCTFP_ERR_SHAPE:
         raise ValueError(msg)            # numpy's reshape failure at src/fingerprint.py:194
     if rc == DCTFP_ERR_NOMEM:
@@ -133,7 +134,7 @@ class Context:
     def __init__(self, device: int, lib=None):
         lib = lib if lib is not None else load()
         handle = C.c_void_p()
-        check(lib.dctfp_create(int(device), C.byref(handle)))
+        check(lib.dctfp_create(int(device), C.byref(handle)), lib)
         self._lib = lib
         self._h = handle
         self.device = int(device)
@@ -156,18 +157,18 @@ class Context:
         return self._h
 
     def set_option(self, name: str, value: int):
-        check(self._lib.dctfp_set_option(self.handle, name.encode(), int(value)))
+        check(self._lib.dctfp_set_option(self.handle, name.encode(), int(value)), self._lib)
 
     def get_option(self, name: str) -> int:
         v = C.c_int64()
-        check(self._lib.dctfp_get_option(self.handle, name.encode(), C.byref(v)))
+        check(self._lib.dctfp_get_option(self.handle, name.encode(), C.byref(v)), self._lib)
         return v.value
 
     def profile(self):
         """(ms[2], launches[2]) of stage A / stage B since the last call ("profile" option on)."""
         ms = (C.c_double * 2)()
         n = (C.c_int64 * 2)()
-        check(self._lib.dctfp_profile(self.handle, ms, n))
+        check(self._lib.dctfp_profile(self.handle, ms, n), self._lib)
         return [ms[0], ms[1]], [n[0], n[1]]
 
 

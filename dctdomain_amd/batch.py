@@ -177,5 +177,5 @@ def quantize_batch(layers: Sequence[LayerBatch], table: PieceTable, out: torch.T
     rc = ctx._lib.dctfp_quantize(ctx.handle, arr, len(layers), n_seq, table.seq_rows.ctypes.data,
                                  table.pieces.ctypes.data, len(table.pieces), table.n_domains,
                                  out.data_ptr() if out_ptr is None else out_ptr, out.stride(0), C.c_void_p(stream.cuda_stream))
-    _lib.check(rc)
+    _lib.check(rc, ctx._lib)
     return out
