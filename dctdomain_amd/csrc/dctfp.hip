@@ -158,7 +158,7 @@ struct EventPair {
 }  // namespace
 
 constexpr int kMaxSlots = 8;
-constexpr size_t kCounterBytes = 16 * sizeof(unsigned long long);  // [0] degenerate channels; [1..11] phase cycles of an instrumented build; [15] device address of the host flag
+constexpr size_t kCounterBytes = 24 * sizeof(unsigned long long);  // [0] degenerate channels; [1..11] phase times of an instrumented build; [15] device address of the host flag; [16], [17] trace of an instrumented build
 
 struct dctfp_ctx {
     int device = 0;
@@ -212,7 +212,9 @@ struct dctfp_ctx {
     unsigned long long* degenerate = nullptr;  // device counter: exactly constant channels seen (see dctfp.h)
     uint32_t* flag_host = nullptr;             // pinned + mapped word the kernels set when they see one (option degenerate_seen)
     int n_cu = 256;  // compute units of the device (workgroup slots of the walk kernel = n_cu x workgroups per CU)
-    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0;
+    void *trace_dev = nullptr, *trace_host = nullptr;  // instrumented build only (walk_trace)
+    int64_t trace_waves = 0;
+    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     int64_t walk_launches = 0;  // walk-kernel launches so far (a call split at a giant domain ends on the two-kernel path)
     int64_t test_fail_once = 0;                    // test hook: the next dctfp_quantize fails after its table lookups
@@ -566,8 +568,19 @@ struct WParams {
 };
 
 template <typename T, int S, int G, int NT, int UNROLL>
-void launch_walk_impl(const WParams& p, bool fused) {
+void launch_walk_impl(const WParams& p, bool fused, bool mfma_a = false) {
     static const InvTab<3> inv = make_inv<3>();
+#ifdef DCTFP_EXPERIMENTS
+    if constexpr (sizeof(T) == 4 && UNROLL == 8 && G == 4) {
+        if (fused && mfma_a) {  // stage A on the matrix pipe (experiment of round 3: DESIGN.md section 4)
+            hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb,
+                               p.walks, p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
+            return;
+        }
+    }
+#else
+    (void)mfma_a;
+#endif
     if (fused)
         hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
                            p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
@@ -577,21 +590,21 @@ void launch_walk_impl(const WParams& p, bool fused) {
 }
 
 template <int S, int G>
-int launch_walk_u(const WParams& p, int unroll, bool fused) {
+int launch_walk_u(const WParams& p, int unroll, bool fused, bool mfma_a) {
     if (unroll == 4) launch_walk_impl<float, S, G, 5, 4>(p, fused);
     else if (unroll == 6) launch_walk_impl<float, S, G, 5, 6>(p, fused);
 #ifdef DCTFP_EXPERIMENTS
-    else if (unroll == 12 && S == 10) launch_walk_impl<float, 10, G, 5, 12>(p, fused);
-    else if (unroll == 16 && S == 10) launch_walk_impl<float, 10, G, 5, 16>(p, fused);
+    else if (unroll == 12 && G == 4) launch_walk_impl<float, S, 4, 5, 12>(p, fused);
+    else if (unroll == 16 && G == 4) launch_walk_impl<float, S, 4, 5, 16>(p, fused);
 #endif
-    else launch_walk_impl<float, S, G, 5, 8>(p, fused);
+    else launch_walk_impl<float, S, G, 5, 8>(p, fused, mfma_a);
     return DCTFP_OK;
 }
 
 // Instantiated shapes: S waves cover up to 256 S channels; G = jobs per flush <= 4 (the rows of an MFMA tile), bounded by
 // the LDS too (2304 B per wave and job: G = 4 leaves room for 17 waves per CU, G = 3 for 23).  A flush costs the same
 // MFMAs for 1..4 jobs, so G = 4 is the default everywhere.  Half-precision rows: the default shape only.
-int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fused) {
+int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fused, bool mfma_a) {
     if (dtype == DCTFP_F16 || dtype == DCTFP_BF16) {
         const bool h = dtype == DCTFP_F16;
         if (s == 3) h ? launch_walk_impl<_Float16, 3, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 3, 4, 5, 8>(p, fused);
@@ -599,12 +612,12 @@ int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fuse
         else h ? launch_walk_impl<_Float16, 10, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 10, 4, 5, 8>(p, fused);
         return DCTFP_OK;
     }
-    if (s == 3 && g == 4) return launch_walk_u<3, 4>(p, unroll, fused);
-    if (s == 3 && g == 3) return launch_walk_u<3, 3>(p, unroll, fused);
-    if (s == 5 && g == 4) return launch_walk_u<5, 4>(p, unroll, fused);
-    if (s == 5 && g == 3) return launch_walk_u<5, 3>(p, unroll, fused);
-    if (s == 10 && g == 4) return launch_walk_u<10, 4>(p, unroll, fused);
-    if (s == 10 && g == 3) return launch_walk_u<10, 3>(p, unroll, fused);
+    if (s == 3 && g == 4) return launch_walk_u<3, 4>(p, unroll, fused, mfma_a);
+    if (s == 3 && g == 3) return launch_walk_u<3, 3>(p, unroll, fused, mfma_a);
+    if (s == 5 && g == 4) return launch_walk_u<5, 4>(p, unroll, fused, mfma_a);
+    if (s == 5 && g == 3) return launch_walk_u<5, 3>(p, unroll, fused, mfma_a);
+    if (s == 10 && g == 4) return launch_walk_u<10, 4>(p, unroll, fused, mfma_a);
+    if (s == 10 && g == 3) return launch_walk_u<10, 3>(p, unroll, fused, mfma_a);
     return fail(DCTFP_ERR_INVALID, "walk kernel: no build for %d waves x %d jobs per flush", s, g);
 }
 
@@ -737,6 +750,25 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         HIP_TRY(hipMemset(ctx->degenerate, 0, kFlagSlot * sizeof(unsigned long long)));  // (slot 15 keeps the flag's address)
         *ctx->flag_host = 0;
     }
+#ifdef DCTFP_WALK_TIMELINE
+    else if (n == "walk_trace") {  // instrumented build: per-wave {begin, end, HW_ID, workgroup} of the next walk launch (value = waves)
+        if (value < 0 || value > (1 << 24)) return fail(DCTFP_ERR_INVALID, "walk_trace must be 0 .. 2^24 waves");
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipDeviceSynchronize());
+        if (ctx->trace_dev) (void)hipFree(ctx->trace_dev);
+        ctx->trace_dev = nullptr;
+        free(ctx->trace_host);
+        ctx->trace_host = nullptr;
+        ctx->trace_waves = value;
+        unsigned long long slots[2] = {(unsigned long long)value, 0};
+        if (value > 0) {
+            HIP_TRY(hipMalloc((void**)&ctx->trace_dev, (size_t)value * 32));
+            HIP_TRY(hipMemset(ctx->trace_dev, 0, (size_t)value * 32));
+            slots[1] = (unsigned long long)(uintptr_t)ctx->trace_dev;
+        }
+        HIP_TRY(hipMemcpy(ctx->degenerate + 16, slots, sizeof slots, hipMemcpyHostToDevice));
+    }
+#endif
 #ifdef DCTFP_EXPERIMENTS
     // ---- engineering knobs and test hooks: libdctfp_experiments.so only (A/B tools, kernel-variant parity tests, cache tests)
     else if (n == "stage_b") {
@@ -764,6 +796,8 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "ab_longest_first") {
         if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "ab_longest_first must be 0 (auto), 1 (on) or 2 (off)");
         ctx->opt_ab_longest_first = value;
+    } else if (n == "ab_mfma_a") {
+        ctx->opt_ab_mfma_a = value ? 1 : 0;
     } else if (n == "ab_run_jobs") {
         if (value < 0 || value > 4096) return fail(DCTFP_ERR_INVALID, "ab_run_jobs must be 0 (auto) .. 4096");
         ctx->opt_ab_run_jobs = value;
@@ -813,6 +847,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     else if (n == "ab_run_jobs") *value = ctx->opt_ab_run_jobs;
     else if (n == "ab_longest_first") *value = ctx->opt_ab_longest_first;
     else if (n == "small_b_jobs") *value = ctx->opt_small_b_jobs;
+    else if (n == "ab_mfma_a") *value = ctx->opt_ab_mfma_a;
     else if (n == "pack_y") *value = ctx->opt_pack_y;
     else if (n == "basis_cap_kb") *value = ctx->basis_cap_doubles / 128;
     else if (n == "basis_restarts") *value = ctx->basis_restarts;
@@ -827,6 +862,15 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(&v, ctx->degenerate + 1 + i, sizeof v, hipMemcpyDeviceToHost));
         *value = (int64_t)v;
+    } else if (n == "walk_trace_host") {  // address of a host copy of the trace (4 x uint64 per wave), valid until the next walk_trace
+        if (!ctx->trace_dev) return fail(DCTFP_ERR_INVALID, "walk_trace_host: no trace (set walk_trace first)");
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipDeviceSynchronize());
+        free(ctx->trace_host);
+        ctx->trace_host = malloc((size_t)ctx->trace_waves * 32);
+        if (!ctx->trace_host) return fail(DCTFP_ERR_NOMEM, "walk_trace_host: out of memory");
+        HIP_TRY(hipMemcpy(ctx->trace_host, ctx->trace_dev, (size_t)ctx->trace_waves * 32, hipMemcpyDeviceToHost));
+        *value = (int64_t)(uintptr_t)ctx->trace_host;
     }
 #endif
     else return fail(DCTFP_ERR_INVALID, "unknown option '%s'", name);
@@ -1367,7 +1411,7 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             wp.degenerate = ctx->degenerate;
             wp.grid = (unsigned)n_runs;
             wp.stream = stream;
-            rc = launch_walk(wp, g.dtype, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : 8, fuse);
+            rc = launch_walk(wp, g.dtype, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : 8, fuse, ctx->opt_ab_mfma_a != 0);
             if (rc) return rc;
             HIP_TRY(hipGetLastError());
             rc = prof_end(ep, stream);

@@ -980,6 +980,39 @@ __device__ inline void wave_min_max48(double& mn, double& mx) {
     mx = fmax(fmax(lane_value(mx, 0), lane_value(mx, 16)), lane_value(mx, 32));
 }
 
+// Transposition of a 4 x 4 arrangement across the four 16-lane rows of a wave: in, lane row g holds r[h]; out, lane row g
+// holds o[i] = (what lane row i held in r[g]), same lane inside the row.  v_permlane32_swap exchanges the upper half of its
+// first operand with the lower half of the second, v_permlane16_swap the odd rows of the first with the even rows of the
+// second (tools/microbench/permlane_swap_probe.hip): two of each per 32-bit register quartet.
+__device__ inline void lane_rows_swap32(uint32_t& a, uint32_t& b) {
+    const v2u32 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+__device__ inline void lane_rows_swap16(uint32_t& a, uint32_t& b) {
+    const v2u32 r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+template <int NOUT>  // the first NOUT (2 or 4) of the transposed values are wanted
+__device__ inline void lane_rows_transpose(const double (&r)[4], double (&o)[NOUT]) {
+    uint32_t w[4][2];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        w[h][0] = (uint32_t)__double2loint(r[h]);
+        w[h][1] = (uint32_t)__double2hiint(r[h]);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        lane_rows_swap32(w[0][c], w[2][c]);  // w0 = [r0.0 r0.1 r2.0 r2.1]   w2 = [r0.2 r0.3 r2.2 r2.3]   (rX.g = lane row g of r[X])
+        lane_rows_swap32(w[1][c], w[3][c]);  // w1 = [r1.0 r1.1 r3.0 r3.1]   w3 = [r1.2 r1.3 r3.2 r3.3]
+        lane_rows_swap16(w[0][c], w[1][c]);  // w0 = [r0.0 r1.0 r2.0 r3.0]   w1 = [r0.1 r1.1 r2.1 r3.1]
+        if constexpr (NOUT > 2) lane_rows_swap16(w[2][c], w[3][c]);  // w2 = [r0.2 r1.2 r2.2 r3.2]   w3 = [r0.3 r1.3 r2.3 r3.3]
+    }
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) o[i] = __hiloint2double((int)w[i][1], (int)w[i][0]);
+}
+
 struct Run {
     uint32_t walk_begin;  // first Walk of this workgroup
     uint32_t n_walks;
@@ -996,18 +1029,19 @@ struct Run {
 #define DCTFP_WALK_B_DEPTH 0         // k-steps of stage-B fragments in flight during a flush: 0 = by shape (below), else 1, 2, 4
 #endif
 
-// Instrumented build (tools/walk_timeline.py; never the shipped library): every wave adds the shader-clock cycles it
+// Instrumented build (tools/walk_timeline.py; never the shipped library): every wave adds the time (s_memrealtime: the
+// constant 100 MHz counter -- the shader clock moves with the power management, by 20 % between variants) it
 // spends per phase to degenerate[1 + phase] -- 0 stream (job record -> last row accumulated), 1 epilogue, 2 flush
 // contraction (unpack + MFMA), 3 wait at the barrier before the cross-wave sum, 4 cross-wave sum + int8, 5 wait at the
 // barrier that frees the slots, 6 everything else, 7 wave lifetime; 8 waves, 9 jobs, 10 flushes.
 #ifdef DCTFP_WALK_TIMELINE
 #define DCTFP_TL_DECL                                   \
-    uint64_t tl_prev = __builtin_amdgcn_s_memtime();    \
+    uint64_t tl_prev = __builtin_amdgcn_s_memrealtime();    \
     const uint64_t tl_begin = tl_prev;                  \
     uint64_t tl_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define DCTFP_TL_MARK(i)                                         \
     do {                                                         \
-        const uint64_t now_ = __builtin_amdgcn_s_memtime();      \
+        const uint64_t now_ = __builtin_amdgcn_s_memrealtime();      \
         tl_acc[i] += now_ - tl_prev;                             \
         tl_prev = now_;                                          \
     } while (0)
@@ -1020,7 +1054,7 @@ struct Run {
 #define DCTFP_TL_ANCHOR(x)
 #endif
 
-template <typename T, int S, int G, int NT, int UNROLL, bool FUSED>
+template <typename T, int S, int G, int NT, int UNROLL, bool FUSED, bool MA = false>
 __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
                                                           const Walk* __restrict__ walks, const Run* __restrict__ runs,
                                                           const PieceA* __restrict__ pieces, const double* __restrict__ stf,
@@ -1057,6 +1091,24 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
     uint32_t group_job = run.job_begin;  // job of slot 0
     DCTFP_TL_DECL
 
+    // MA, rare path: bit e = my channel e differs somewhere in the job from the job's first row (an exactly constant
+    // channel has no bit: its F must be exactly 0).  One more pass over the job's rows, by the whole wave.
+    auto differs_from_first_row = [&](const JobA& jb) {
+        const PieceA* __restrict__ pcs = pieces + jb.piece_begin;
+        const Rw r0 = load_raw<T, VEC>(reinterpret_cast<const T*>(pcs[0].ptr) + colc);
+        uint32_t dif = 0;
+        for (uint32_t p = 0; p < jb.n_pieces; ++p) {
+            const PieceA piece = pcs[p];
+            const __amdgpu_buffer_rsrc_t rows = wave_buffer(piece.ptr);
+            for (uint32_t r = 0; r < piece.n_rows; ++r) {
+                const Rw x = buffer_load_raw<Rw, false>(rows, col_bytes, (int)r * ld_bytes);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) dif |= (raw_elem<T, VEC>(x, e) != raw_elem<T, VEC>(r0, e) ? 1u : 0u) << e;
+            }
+        }
+        return dif;
+    };
+
     for (uint32_t wi = 0; wi < run.n_walks; ++wi) {
         const Walk wk = walks[run.walk_begin + wi];
         const bool has_w = FUSED && wk.whole_job >= 0;
@@ -1068,6 +1120,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
             for (int k = 0; k < (FUSED ? NK : 1); ++k) wacc[k][v] = 0.0;
         // rows of the whole protein = offset of the prefix sums behind its cosine table
         const uint32_t w_rows = has_w ? jobs[wk.whole_job].n_rows : 0u;
+        uint32_t w_suspect = 0xfu;  // MA: bit e = my channel e was within the round-off bound of a constant channel in every part so far
 
         for (uint32_t part = 0; part < n_walk_jobs; ++part) {
             double f[NK][VEC];
@@ -1077,6 +1130,117 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 // ---- stage A of one job: every row of this wave's 256 channels
                 const JobA job = jobs[wk.job_begin + part];
                 const PieceA* __restrict__ pc = pieces + job.piece_begin;
+                if constexpr (MA) {
+                // ---- the multiply-adds of stage A on the matrix pipe (fused walks of float32 rows).  The fused walks run the
+                // package into its power limit; a float64 multiply-add costs 2.6 x less energy in an MFMA
+                // than in v_fma_f64 (tools/microbench/power_pipes.hip, stage_a_pipes.hip).  One load instruction fetches 4
+                // consecutive rows x 64 channels: lane (q, g) = (lane & 15, lane >> 4) reads row r + g, the 16 bytes lane
+                // 16 h + q of the vector layout owns (chunk h = 0..3: the same two 512-byte segments per row and wave as
+                // before, in 256-byte halves) -- which IS the B operand layout B[k = lane >> 4][j = lane & 3] of the four
+                // 4 x 4 x 4 blocks, no shuffle.  The A operand A[i = lane & 3][k = lane >> 4] is one double per lane and 4-row
+                // step: cos of {part k=1, part k=2, whole k=1, whole k=2} at row r + k, straight from the cosine tables.
+                // D[i = lane >> 4][j]: 16 MFMAs per step leave 4 outputs x 256 channels in macc.  Per element that is one
+                // v_cvt_f64_f32 and a sixteenth of an MFMA -- no subtraction: the cosines of a job sum to zero, so the first-row
+                // shift of the vector path only matters for an exactly constant channel (which must give exactly 0, not the
+                // round-off of sum c(t) x).  That case is caught afterwards: |F| below the round-off bound of a constant channel
+                // -> the wave re-reads the job and compares (never_differs, below); no healthy channel comes near the bound.
+                static_assert(!MA || (FUSED && sizeof(T) == 4 && VEC == 4 && UNROLL % 4 == 0), "matrix-pipe stage A: fused walks of float32 rows");
+                const int mq = lane & 15, mg = lane >> 4;
+                int mcol[4];  // my 16 bytes inside a row, per chunk
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int p0 = wave * (WCH / 2) + 64 * (h & 1) + VEC * mq;
+                    mcol[h] = (p0 >= half ? 0 : (h >= 2 ? n_cols - VEC - p0 : p0)) * (int)sizeof(T);
+                }
+                const int n_act = (half - wave * (WCH / 2) + 63) / 64;  // chunk pairs (h, h + 2) that hold channels: <= 0, 1, >= 2
+                // macc[h][e]: lane (q, i = lane >> 4) holds output i (0, 1: the part's F1, F2; 2, 3: the whole protein's share of this
+                // part) of channel colc(lane 16 h + q) + e
+                double macc[4][4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) macc[h][e] = 0.0;
+                // (my channels' first row, for the round-off bound at the end: asked for now, its latency under the stream's)
+                const Rw rp = load_raw<T, VEC>(reinterpret_cast<const T*>(pc[0].ptr) + colc);
+                typedef const double __attribute__((address_space(1))) * GD;
+                auto stream_piece = [&](auto nch_tag, const PieceA& piece) {
+                    constexpr int NCH = decltype(nch_tag)::value;
+                    const __amdgpu_buffer_rsrc_t rows = wave_buffer(piece.ptr);
+                    const bool whole_lane = has_w && (lane & 2);  // (a walk without whole protein: outputs 2, 3 repeat 0, 1, unused)
+                    const GD ap = (GD)(uintptr_t)((whole_lane ? job.w_basis + (size_t)piece.w0 * NK : job.basis + (size_t)piece.t0 * NK) +
+                                                  mg * NK + (lane & 1));
+                    auto load_step = [&](Rw (&x)[4], int lane_rows, uint32_t r) {
+#pragma unroll
+                        for (int h = 0; h < 4; ++h)
+                            if ((h & 1) < NCH) x[h] = buffer_load_raw<Rw, true>(rows, mcol[h] + lane_rows, (int)r * ld_bytes);
+                    };
+                    auto step = [&](const Rw (&x)[4], double a) {
+#pragma unroll
+                        for (int h = 0; h < 4; ++h)
+                            if ((h & 1) < NCH) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    macc[h][e] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, (double)x[h][e], macc[h][e], 0, 0, 0);
+                            }
+                    };
+                    constexpr int STEPS = UNROLL / 4;
+                    const int my_rows = mg * ld_bytes;
+                    uint32_t r = 0;
+                    for (; r + 4 * STEPS <= piece.n_rows; r += 4 * STEPS) {
+                        Rw x[STEPS][4];
+                        double a[STEPS];
+#pragma unroll
+                        for (int st = 0; st < STEPS; ++st) {
+                            load_step(x[st], my_rows, r + 4 * st);
+                            a[st] = ap[(size_t)(r + 4 * st) * NK];
+                        }
+#pragma unroll
+                        for (int st = 0; st < STEPS; ++st) step(x[st], a[st]);
+                    }
+                    if (r < piece.n_rows) {  // the last 1-7 rows in one round of loads: the lanes past the end repeat the piece's
+                        const int rem = (int)(piece.n_rows - r);  // last row with cosine 0
+                        const int rr0 = min(mg, rem - 1), rr1 = min(4 + mg, rem - 1);
+                        Rw x[2][4];
+                        load_step(x[0], rr0 * ld_bytes, r);
+                        const double a0 = ap[((int64_t)r + rr0 - mg) * NK];
+                        double a1 = 0.0;
+                        if (rem > 4) {
+                            load_step(x[1], rr1 * ld_bytes, r);
+                            a1 = ap[((int64_t)r + rr1 - mg) * NK];
+                        }
+                        step(x[0], mg < rem ? a0 : 0.0);
+                        if (rem > 4) step(x[1], 4 + mg < rem ? a1 : 0.0);
+                    }
+                };
+                for (uint32_t p = 0; p < job.n_pieces; ++p) {
+                    const PieceA piece = pc[p];
+                    if (n_act >= 2) stream_piece(std::integral_constant<int, 2>{}, piece);
+                    else if (n_act == 1) stream_piece(std::integral_constant<int, 1>{}, piece);
+                }
+                // back to the vector layout: lane l = 16 g + q owns colc(l) + e = the channels of chunk g -> after the lane-row
+                // transposition of macc[0..3][e] every lane holds the four outputs of its own channel e.
+                uint32_t suspect = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double r4[4] = {macc[0][e], macc[1][e], macc[2][e], macc[3][e]};
+                    double o[4];
+                    lane_rows_transpose<4>(r4, o);
+                    f[0][e] = o[0];
+                    f[1][e] = o[1];
+                    wacc[0][e] += o[2];
+                    wacc[1][e] += o[3];
+                    // round-off of an exactly constant channel: |sum c(t) x| <= |x| (L 2^-51 + L^2 2^-54); 16 x that
+                    const double bound = fabs((double)rp[e]) * ((double)job.n_rows * (double)job.n_rows) * 0x1p-50;
+                    suspect |= (fabs(o[0]) <= bound && fabs(o[1]) <= bound ? 1u : 0u) << e;
+                }
+                w_suspect &= suspect;  // a channel constant over the whole protein is constant in every part
+                if (__builtin_amdgcn_ballot_w64(suspect != 0 && !pad) != 0) {
+                    const uint32_t dif = differs_from_first_row(job);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!((dif >> e) & 1)) f[0][e] = f[1][e] = 0.0;
+                }
+                } else {
                 double ref[VEC];
 #pragma unroll
                 for (int k = 0; k < NK; ++k)
@@ -1172,6 +1336,19 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                     }
                 }
                 }  // !pad
+                }  // !MA
+            } else if constexpr (MA) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f[0][e] = wacc[0][e];
+                    f[1][e] = wacc[1][e];
+                }
+                if (__builtin_amdgcn_ballot_w64(w_suspect != 0 && !pad) != 0) {
+                    const uint32_t dif = differs_from_first_row(jobs[wk.whole_job]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!((dif >> e) & 1)) f[0][e] = f[1][e] = 0.0;
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < NK; ++k)
@@ -1194,8 +1371,10 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                     c4 |= code << (8 * v);
                     __builtin_amdgcn_sched_barrier(0);  // one channel at a time (register pressure)
                 }
-                *reinterpret_cast<v4d*>(&lds_t[wave][pending][VEC * lane]) = (v4d){tv[0], tv[1], tv[2], tv[3]};
-                lds_c[wave][pending][lane] = c4;
+                int sl = lane;
+                if constexpr (MA) asm volatile("" : "+v"(sl));
+                *reinterpret_cast<v4d*>(&lds_t[wave][pending][VEC * sl]) = (v4d){tv[0], tv[1], tv[2], tv[3]};
+                lds_c[wave][pending][sl] = c4;
             }
             ++pending;
             DCTFP_TL_MARK(1);
@@ -1247,7 +1426,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 // k-step took 2 600 cycles against 255 of its 15 MFMAs (tools/walk_timeline.py, profiles/r03).
                 // As deep as the registers allow without spilling (the loads go through a buffer descriptor: no address
                 // registers): 4 steps where the budget is 168 registers (10 waves), 2 where the kernel carries no second accumulator set.
-                constexpr int DEPTH = DCTFP_WALK_B_DEPTH ? DCTFP_WALK_B_DEPTH : (S >= 10 ? 4 : (FUSED ? 1 : 2));
+                constexpr int DEPTH = DCTFP_WALK_B_DEPTH ? DCTFP_WALK_B_DEPTH : (S >= 10 ? (MA ? 2 : 4) : (FUSED ? 1 : 2));
                 static_assert(DEPTH == 1 || DEPTH == 2 || DEPTH == 4, "slot of a k-step must be static under the 4-step unroll");
                 double bq[DEPTH][NT];
                 if (n_q > 0) {
@@ -1298,6 +1477,10 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
             // float32 variants at the 128-register budget take them one by one (together they spill 4 registers per lane).
             constexpr int ROWS = (FUSED && S < 10 && sizeof(T) == 4) ? 1 : 3;
             auto finish_job = [&](uint32_t g) {
+                // (MA: the lane index through an opaque copy, like the flush above -- the store offsets and masks derived from it
+                //  would otherwise be computed at the top of the kernel and held in ~20 registers through the row stream)
+                int lane = threadIdx.x & 63;
+                if constexpr (MA) asm volatile("" : "+v"(lane));
                 const int hm = (m + 1) >> 1;
                 const bool valid0 = lane < hm;
                 const bool valid1 = lane < hm && (m - 1 - lane) != lane;  // odd m: the middle column is its own mirror (O = 0 there)
@@ -1350,8 +1533,20 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
     tl_acc[7] = tl_prev - tl_begin;
     tl_acc[8] = 1;
     if (lane == 0) {
+        // per-wave trace (option walk_trace, tools/walk_trace.py): begin, end, where it ran, which workgroup -- instead of the
+        // phase sums (100 000 waves adding to the same eleven words stretch the launch they are meant to describe)
+        unsigned long long* __restrict__ trace = reinterpret_cast<unsigned long long*>((uintptr_t)degenerate[17]);
+        const unsigned long long idx = (unsigned long long)blockIdx.x * S + wave;
+        if (!trace) {
 #pragma unroll
-        for (int i = 0; i < 11; ++i) atomicAdd(degenerate + 1 + i, (unsigned long long)tl_acc[i]);
+            for (int i = 0; i < 11; ++i) atomicAdd(degenerate + 1 + i, (unsigned long long)tl_acc[i]);
+        } else if (idx < degenerate[16]) {
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_ID, XCC_ID
+            trace[4 * idx + 0] = tl_begin;
+            trace[4 * idx + 1] = tl_prev;
+            trace[4 * idx + 2] = ((unsigned long long)xcc << 32) | hw;
+            trace[4 * idx + 3] = ((unsigned long long)blockIdx.x << 32) | (unsigned)wave;
+        }
     }
 #endif
 }

@@ -262,3 +262,61 @@ def test_one_giant_domain_does_not_take_the_call_off_the_walk_kernel(dd):
         ref = dd.quantize_batch(lbs, table).cpu().numpy()
     np.testing.assert_array_equal(out, ref)
     _check_oracle(out, table, layers, offs, lens, doms, (5, 16, 17, 18, 200, 299))
+
+
+@pytest.mark.parametrize('D', [640, 1280, 2560])
+def test_matrix_pipe_stage_a_matches_the_vector_path(dd, D):
+    """Round-3 experiment kept as an engineering knob of libdctfp_experiments.so (`ab_mfma_a`): the multiply-adds of stage A of
+    the fused walks as v_mfma_f64_4x4x4 on 4-row x 64-channel loads, without the first-row shift.  Same bytes as the
+    vector path on RecCut-shaped proteins (parts of 3 .. 130 rows that are no multiples of 4, discontinuous domains) --
+    including the inputs the shift exists for: channels that are exactly constant over a part, over a whole protein, as
+    +0.0 / -0.0, next to a channel that differs from a constant in one bit of one row, and a channel holding a NaN."""
+    import torch
+    from dctdomain_amd import _lib
+    rng = np.random.default_rng(1000 + D)
+    lens, doms = [], []
+    for i in range(96):
+        n_parts = int(rng.integers(2, 7))
+        parts = [int(v) for v in (rng.integers(3, 8, size=n_parts) if i % 3 == 0 else rng.integers(9, 131, size=n_parts))]
+        edges = np.concatenate([[0], np.cumsum(parts)])
+        L = int(edges[-1])
+        dl = [f'{a + 1}-{b}' for a, b in zip(edges[:-1], edges[1:])]
+        if len(dl) >= 3 and i % 4 == 1:
+            dl = [dl[0] + ',' + dl[-1]] + dl[1:-1]            # first + last part as one discontinuous domain
+        lens.append(L)
+        doms.append(dl + [f'1-{L}'])
+    layers, offs = _device_batch(torch, lens, D, 2, 4242 + D)
+    first_rows = {}
+    for s in range(0, 96, 2):                                  # every other protein carries one kind of special channel
+        a, b = int(offs[s]), int(offs[s]) + lens[s]
+        pa, pb = (int(v) for v in doms[s][1].split(',')[0].split('-'))     # second domain: one piece
+        for k, x in enumerate(layers):
+            if s % 8 == 0:                                     # constant over the whole protein (one channel in each half)
+                x[a:b, 3] = 1.25 + k
+                x[a:b, D - 5] = 7.0
+            elif s % 8 == 2:                                   # constant over one part only: the other domains keep their bytes
+                x[a + pa - 1:a + pb, 7] = -3.5
+            elif s % 8 == 4:                                   # +0.0 / -0.0: equal as numbers, constant
+                x[a:b, 11] = 0.0
+                x[a:b:2, 11] = -0.0
+            else:                                              # one bit in one row: NOT constant; and a NaN
+                x[a:b, 19] = 2.0
+                x[a + lens[s] // 2, 19] = float(np.nextafter(np.float32(2.0), np.float32(3.0)))
+                if s % 16 == 6:
+                    x[a + 1, 23] = float('nan')
+        first_rows[s] = a
+    table = dd.PieceTable(lens, doms)
+    assert 2 * table.n_domains >= 256
+    lbs = [dd.LayerBatch(x, 3, 80, row_offsets=offs) for x in layers]
+    xctx = _lib.experiments_context(torch.cuda.current_device())
+    got = {}
+    for flag in (0, 1):
+        with _Options(xctx, ab_mfma_a=flag, path=2):
+            xctx.set_option('degenerate_channels', 0)
+            out = dd.quantize_batch(lbs, table, ctx=xctx).cpu().numpy()
+            assert xctx.get_option('last_path') == 2
+            got[flag] = (out, xctx.get_option('degenerate_channels'))
+    assert got[0][1] > 0 and got[1][1] == got[0][1], (got[0][1], got[1][1])      # the same channels were found constant
+    np.testing.assert_array_equal(got[1][0], got[0][0])
+    # ... and both are the product library's bytes
+    np.testing.assert_array_equal(dd.quantize_batch(lbs, table).cpu().numpy(), got[0][0])

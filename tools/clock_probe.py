@@ -1,5 +1,6 @@
 """Is the chip at its clock while the walk kernel runs?  Loops one workload for a few seconds and samples
-`rocm-smi --showclocks --showpower` from a side thread.  usage: python tools/clock_probe.py c2 c4 c5"""
+`rocm-smi --showclocks --showpower` from a side thread.  usage: python tools/clock_probe.py c2 c4 c5 [name=value ...]
+(options need the experiments library: DCTFP_LIBRARY=dctdomain_amd/libdctfp_experiments.so)"""
 import os, subprocess, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,6 +9,9 @@ import bench
 
 dev = torch.device('cuda', 0)
 ctx = dd.get_context(0)
+for kv in [a for a in sys.argv[1:] if '=' in a]:
+    ctx.set_option(kv.split('=')[0], int(kv.split('=')[1]))
+sys.argv = [a for a in sys.argv if '=' not in a]
 nseq = {'c2': 10000, 'c3': 10000, 'c4': 12000, 'c5': 40000}
 
 
@@ -46,7 +50,12 @@ for w in sys.argv[1:] or ['c2', 'c4', 'c5']:
     dt = (time.perf_counter() - t0) / n
     stop.set(); th.join()
     print(f'== {w}: {1e3 * dt:.3f} ms per step = {nbytes / dt / 1e9:.0f} GB/s over {n} steps')
+    import json
     for s in samples[1:6]:
-        print('   ', ' '.join(s.split()))
+        try:
+            d = json.loads(s)['card0']
+            print('    sclk', d.get('sclk clock speed:'), ' power', d.get('Current Socket Graphics Package Power (W)'), 'W')
+        except Exception:     # noqa: BLE001
+            print('   ', ' '.join(s.split())[:300])
     del layers, lbs, out
     torch.cuda.empty_cache()

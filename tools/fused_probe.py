@@ -11,8 +11,11 @@ layers = [torch.randn((n_seq * L, D), device=dev) for _ in range(2)]
 offs = np.arange(n_seq, dtype=np.int64) * L
 lbs = [dd.LayerBatch(x, 3, 80, row_offsets=offs) for x in layers]
 ctx = dd.get_context(0)
-if len(sys.argv) > 2:
-    ctx.set_option('overlap', int(sys.argv[2]))
+for arg in sys.argv[2:]:   # an overlap count, or name=value options of the experiments library (ab_mfma_a=1 ...)
+    if '=' in arg:
+        ctx.set_option(arg.split('=')[0], int(arg.split('=')[1]))
+    else:
+        ctx.set_option('overlap', int(arg))
 def parts(k):
     e = [round(i * L / k) for i in range(k + 1)]
     return [f'{a + 1}-{b}' for a, b in zip(e[:-1], e[1:])]

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs tools/microbench/stage_a_pipes.hip variant by variant and samples clocks + package power beside each (GPU box).
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/stage_a_pipes tools/microbench/stage_a_pipes.hip 2>/dev/null || exit 1
+for mode in ${@:-read read_direct valu24 mfma_direct}; do
+    /tmp/stage_a_pipes $mode 7 > /tmp/sap_$mode.txt &
+    PID=$!
+    sleep 3
+    for i in 1 2 3; do
+        rocm-smi --showclocks --showpower --json 2>/dev/null | python3 -c "
+import json, sys
+d = json.load(sys.stdin)['card0']
+print('    sclk', d.get('sclk clock speed:'), ' power', d.get('Current Socket Graphics Package Power (W)'), 'W')"
+        sleep 1
+    done
+    wait $PID
+    cat /tmp/sap_$mode.txt
+done

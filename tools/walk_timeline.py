@@ -4,8 +4,9 @@ Needs an instrumented build of the library (never the shipped one):
     tools/build_variant.sh timeline -DDCTFP_WALK_TIMELINE -DDCTFP_EXPERIMENTS
     DCTFP_LIBRARY=build_variants/timeline.so python tools/walk_timeline.py c2 c4 c5 [name=value,...]
 
-Every wave adds the shader-clock cycles between its phase marks to device counters (kernels.hip.h, DCTFP_TL_MARK);
-the table is the share of the summed wave lifetimes, plus cycles per job / per flush."""
+Every wave adds the time between its phase marks (s_memrealtime, 10 ns ticks) to device counters (kernels.hip.h,
+DCTFP_TL_MARK); the table is the share of the summed wave lifetimes, plus microseconds per job / per flush, and how much of
+the launch the wave slots of the chip were occupied (sum of lifetimes / (step x resident waves))."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tools._experiments  # noqa: F401  (engineering knobs: libdctfp_experiments.so unless DCTFP_LIBRARY says otherwise)
@@ -48,12 +49,13 @@ for w in workloads:
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
         c = [ctx.get_option(f'walk_timeline_{i}') for i in range(11)]
         life, waves, jobs, flushes = c[7], c[8], c[9], c[10]
+        tick = 1e-8   # s_memrealtime: 100 MHz
         print(f'\n{w}  {cfg}  D={D}  {table.n_domains} fingerprints  step {1e3 * dt:.3f} ms = {nbytes / dt / 1e9:.0f} GB/s   '
               f'{waves // steps} waves, {jobs // steps} wave-jobs, {flushes // steps} wave-flushes per step; '
-              f'mean wave lifetime {life / max(1, waves):.0f} cycles')
+              f'mean wave lifetime {1e6 * tick * life / max(1, waves):.1f} us; sum of lifetimes / step = {tick * life / steps / dt:.0f} waves resident on average')
         for i, name in enumerate(PHASES):
-            per = c[i] / max(1, flushes if i in (2, 3, 4, 5) else jobs)
-            print(f'  {name:34s} {100.0 * c[i] / max(1, life):5.1f} %   {per:9.0f} cycles per {"flush" if i in (2, 3, 4, 5) else "job"}')
+            per = 1e6 * tick * c[i] / max(1, flushes if i in (2, 3, 4, 5) else jobs)
+            print(f'  {name:34s} {100.0 * c[i] / max(1, life):5.1f} %   {per:9.2f} us per {"flush" if i in (2, 3, 4, 5) else "job"}')
         for k, v in saved.items():
             ctx.set_option(k, v)
     del layers, lbs, out
