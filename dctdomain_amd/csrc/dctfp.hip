@@ -214,7 +214,7 @@ struct dctfp_ctx {
     int n_cu = 256;  // compute units of the device (workgroup slots of the walk kernel = n_cu x workgroups per CU)
     void *trace_dev = nullptr, *trace_host = nullptr;  // instrumented build only (walk_trace)
     int64_t trace_waves = 0;
-    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0;
+    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0, opt_ab_taper = 4;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     int64_t walk_launches = 0;  // walk-kernel launches so far (a call split at a giant domain ends on the two-kernel path)
     int64_t test_fail_once = 0;                    // test hook: the next dctfp_quantize fails after its table lookups
@@ -788,7 +788,7 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         ctx->opt_ab_group = value;
     } else if (n == "ab_unroll") {
         if (value != 0 && value != 4 && value != 6 && value != 8 && value != 12 && value != 16)
-            return fail(DCTFP_ERR_INVALID, "ab_unroll must be 0 (auto), 4, 6, 8 (12, 16: D > 1280 only)");
+            return fail(DCTFP_ERR_INVALID, "ab_unroll must be 0 (auto), 4, 6, 8, 12 or 16");
         ctx->opt_ab_unroll = value;
     } else if (n == "small_b_jobs") {
         if (value < 0 || value > 1 << 20) return fail(DCTFP_ERR_INVALID, "small_b_jobs must be 0 .. 2^20");
@@ -796,6 +796,9 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "ab_longest_first") {
         if (value < 0 || value > 2) return fail(DCTFP_ERR_INVALID, "ab_longest_first must be 0 (auto), 1 (on) or 2 (off)");
         ctx->opt_ab_longest_first = value;
+    } else if (n == "ab_taper") {
+        if (value < 0 || value > 64) return fail(DCTFP_ERR_INVALID, "ab_taper must be 0 (off) .. 64 (quarters of a round of workgroups whose jobs go out in short runs)");
+        ctx->opt_ab_taper = value;
     } else if (n == "ab_mfma_a") {
         ctx->opt_ab_mfma_a = value ? 1 : 0;
     } else if (n == "ab_run_jobs") {
@@ -848,6 +851,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
     else if (n == "ab_longest_first") *value = ctx->opt_ab_longest_first;
     else if (n == "small_b_jobs") *value = ctx->opt_small_b_jobs;
     else if (n == "ab_mfma_a") *value = ctx->opt_ab_mfma_a;
+    else if (n == "ab_taper") *value = ctx->opt_ab_taper;
     else if (n == "pack_y") *value = ctx->opt_pack_y;
     else if (n == "basis_cap_kb") *value = ctx->basis_cap_doubles / 128;
     else if (n == "basis_restarts") *value = ctx->basis_restarts;
@@ -1189,17 +1193,28 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
                     while (want > walk_g && n_jobs / want < 8192) want -= walk_g;  // ... but ten rounds of workgroups at least
                 }
             }
+            // The end of the launch: its last workgroups run on a chip that is emptying (tools/walk_trace.py: the last 5 % of a
+            // c5 launch hold 15 % of the waves), for as long as ONE workgroup lives.  The jobs of the last round of workgroups
+            // therefore go out in runs of one flush group: four times as many workgroups, a quarter as long.
+            int64_t taper_from = n_jobs;  // runs that start at or after this job are short
+            if (want > walk_g && ctx->opt_ab_taper) {
+                const int64_t slots = (int64_t)ctx->n_cu * (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));
+                taper_from = std::max<int64_t>(0, n_jobs - slots * want * ctx->opt_ab_taper / 4);
+            }
+            int64_t jobs_done = 0;
             for (int64_t w = 0; w < n_walks;) {
                 Run& rn = hrun[n_runs++];
                 rn.walk_begin = (uint32_t)w;
                 rn.job_begin = hwalk[w].job_begin;
                 uint32_t jobs_in = 0;
-                while (w < n_walks && (jobs_in == 0 || (int64_t)jobs_in < want)) {
+                const int64_t want_here = jobs_done >= taper_from ? walk_g : want;
+                while (w < n_walks && (jobs_in == 0 || (int64_t)jobs_in < want_here)) {
                     jobs_in += hwalk[w].n_parts + (hwalk[w].whole_job >= 0 ? 1u : 0u);
                     ++w;
                 }
                 rn.n_walks = (uint32_t)(w - rn.walk_begin);
                 rn.n_jobs = jobs_in;
+                jobs_done += jobs_in;
             }
             // Longest run first, for batches of domains at D > 1280 (one workgroup per CU: 256 slots, so the last round
             // weighs most): the workgroups that start last are the short ones and the chip drains together (c4 +2.8 %).

@@ -214,8 +214,12 @@ int dctfp_stream_synchronize(void* stream);
  * under tools/, kernel-variant parity tests); libdctfp.so answers DCTFP_ERR_INVALID "unknown option" to them.  Their
  * defaults are what is measured and shipped:
  *   "ab_group"     walk kernel: jobs per stage-B flush (0 = auto = 4, 3, 4)
- *   "ab_unroll"    walk kernel: rows in flight per wave (0 = 8; 4, 6, 8; float32 rows only)
+ *   "ab_unroll"    walk kernel: rows in flight per wave (0 = 8; 4, 6, 8, 12, 16; float32 rows only)
  *   "ab_run_jobs"  walk kernel: jobs per workgroup (0 = by the bytes per job and the size of the call)
+ *   "ab_taper"     walk kernel: the jobs of the last N quarter-rounds of workgroups go out in workgroups of one flush
+ *                  group, so that the launch ends evenly (default 4 = one round; 0 = off)
+ *   "ab_mfma_a"    walk kernel, fused walks of float32 rows: 1 = the multiply-adds of stage A as v_mfma_f64_4x4x4 on
+ *                  4-row x 64-channel loads, no first-row shift (an experiment of round 3: same bytes, same rate; default 0)
  *   "ab_longest_first" walk kernel: workgroups ordered by the rows they stream, longest first (0 = auto: batches of
  *                  domains at D > 1280, 1 = always, 2 = never)
  *   "small_b_jobs" two-kernel path: calls with fewer jobs (layers x domains) than this run stage B over 64-channel slabs
@@ -227,6 +231,10 @@ int dctfp_stream_synchronize(void* stream);
  *                  next sub-chunk's stage A (1 = off, default 4)
  *   "pack_y"       two-kernel path, 1 (default) = n = 3: the scratch between the kernels holds {0, t, 1} as one
  *                  float64 + 2-bit states per channel (9 bytes instead of 24)
+ *
+ * Instrumented build only (-DDCTFP_WALK_TIMELINE, tools/build_variant.sh; never shipped): "walk_timeline_0" .. "_10" read the
+ * time (10 ns ticks) the waves of the walk kernel spent per phase; "walk_trace" = N records {begin, end, HW_ID, workgroup}
+ * of every wave of the next launch, "walk_trace_host" = address of a host copy (tools/walk_timeline.py, tools/walk_trace.py).
  *
  * Test hooks (libdctfp_experiments.so only; tests/test_context_cache.py, tests/asan/driver.cpp):
  *   "basis_cap_kb" size of the cosine-table arena at which it starts over (default 1 GiB); "basis_restarts" /
