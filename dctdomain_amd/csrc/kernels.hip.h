@@ -1143,7 +1143,10 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 // v_cvt_f64_f32 and a sixteenth of an MFMA -- no subtraction: the cosines of a job sum to zero, so the first-row
                 // shift of the vector path only matters for an exactly constant channel (which must give exactly 0, not the
                 // round-off of sum c(t) x).  That case is caught afterwards: |F| below the round-off bound of a constant channel
-                // -> the wave re-reads the job and compares (never_differs, below); no healthy channel comes near the bound.
+                // -> the wave re-reads the job and compares (differs_from_first_row, above); no healthy channel comes near the bound.
+                // Outcome: same bytes, a quarter of the vector instructions, 6-11 % more shader clock -- and the
+                // same kernel time to 0.1 %: the fused walks do not hang on the clock.  Kept as an experiment (libdctfp_experiments.so,
+                // option ab_mfma_a); at four waves per SIMD it spills, so A/B it in a build with -DDCTFP_WALK_MIN_WAVES=3.
                 static_assert(!MA || (FUSED && sizeof(T) == 4 && VEC == 4 && UNROLL % 4 == 0), "matrix-pipe stage A: fused walks of float32 rows");
                 const int mq = lane & 15, mg = lane >> 4;
                 int mcol[4];  // my 16 bytes inside a row, per chunk
