@@ -1913,10 +1913,10 @@ int dctfp_l1_matrix(dctfp_ctx* ctx, const int8_t* a, int64_t na, int64_t lda, co
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (na < 0 || nb < 0 || d < 1 || lda < d || ldb < d || ldo < nb) return fail(DCTFP_ERR_INVALID, "dctfp_l1_matrix: bad shape");
     if (na == 0 || nb == 0) return DCTFP_OK;
-    if ((na + 63) / 64 > 65535) return fail(DCTFP_ERR_LIMIT, "dctfp_l1_matrix: more than 4M rows per call");
+    if ((na + 127) / 128 > 65535) return fail(DCTFP_ERR_LIMIT, "dctfp_l1_matrix: more than 8M rows per call");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_v;
-    dim3 grid((unsigned)((nb + 63) / 64), (unsigned)((na + 63) / 64));
+    dim3 grid((unsigned)((nb + 127) / 128), (unsigned)((na + 127) / 128));  // 128 x 128 distances per workgroup (l1_matrix_kernel)
     const bool aligned = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | (uintptr_t)lda | (uintptr_t)ldb) & 3u) == 0;
     if (aligned) hipLaunchKernelGGL((l1_matrix_kernel<true>), grid, dim3(256), 0, stream, a, na, lda, b, nb, ldb, d, out, ldo);
     else hipLaunchKernelGGL((l1_matrix_kernel<false>), grid, dim3(256), 0, stream, a, na, lda, b, nb, ldb, d, out, ldo);

@@ -1997,53 +1997,71 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(256) void l1_matrix_kernel(const int8_t* __restrict__ a, int64_t na, int64_t lda,
                                                          const int8_t* __restrict__ b, int64_t nb, int64_t ldb, int d,
                                                          int32_t* __restrict__ out, int64_t ldo) {
-    constexpr int KC = 128;  // dwords per chunk
-    __shared__ uint32_t sa[64][KC + 1];
-    __shared__ uint32_t sb[64][KC + 1];
-    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    // 128 x 128 distances per workgroup, 8 x 8 per thread: 16 LDS reads per 64 v_sad_u8 (the 4 x 4 tile of round 1 read 8 per
+    // 16 and sat on the LDS).  Thread (ty, tx) owns rows 8 ty .. 8 ty + 7 and columns 8 tx .. 8 tx + 7 -- eight consecutive
+    // int32 per row, so a wave writes whole 512-byte row segments -- and the b rows sit in LDS in the order the lanes read them
+    // (row r at slot (r % 8) * 16 + r / 8: the 16 lanes of a row group read 16 consecutive slots, no bank conflict at the odd
+    // row stride; the a rows are broadcast reads).
+    constexpr int KC = 32, TILE = 128;  // dwords per chunk, rows / columns per workgroup
+    __shared__ uint32_t sa[TILE][KC + 1];
+    __shared__ uint32_t sb[TILE][KC + 1];
+    const int64_t r0 = (int64_t)blockIdx.y * TILE, c0 = (int64_t)blockIdx.x * TILE;
     const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-    uint32_t acc[4][4] = {};
+    uint32_t acc[8][8] = {};
     const int nd = (d + 3) / 4;
     for (int k0 = 0; k0 < nd; k0 += KC) {
         const int kn = min(KC, nd - k0);
         __syncthreads();
-        for (int i = threadIdx.x; i < 64 * kn; i += 256) {
-            const int r = i / kn, k = i % kn;
+        {   // thread -> dword k = tid & 31 of the rows tid >> 5, + 8, + 16, ...: 128 consecutive bytes of a row per 32 lanes
+            const int k = threadIdx.x & (KC - 1);
             const int byte0 = (k0 + k) * 4;
             const int valid = min(4, d - byte0);
-            uint32_t va = 0x80808080u, vb = 0x80808080u;
-            if (r0 + r < na) {
-                const int8_t* p = a + (r0 + r) * lda + byte0;
-                va = (ALIGNED && valid == 4) ? *reinterpret_cast<const uint32_t*>(p) : load_bytes4(p, valid);
+            if (k < kn) {
+#pragma unroll 4
+                for (int r = threadIdx.x >> 5; r < TILE; r += 256 / KC) {
+                    uint32_t va = 0x80808080u, vb = 0x80808080u;
+                    if (r0 + r < na) {
+                        const int8_t* p = a + (r0 + r) * lda + byte0;
+                        va = (ALIGNED && valid == 4) ? *reinterpret_cast<const uint32_t*>(p) : load_bytes4(p, valid);
+                    }
+                    if (c0 + r < nb) {
+                        const int8_t* p = b + (c0 + r) * ldb + byte0;
+                        vb = (ALIGNED && valid == 4) ? *reinterpret_cast<const uint32_t*>(p) : load_bytes4(p, valid);
+                    }
+                    sa[r][k] = va ^ 0x80808080u;  // signed -> unsigned order, |x - y| unchanged
+                    sb[(r & 7) * 16 + (r >> 3)][k] = vb ^ 0x80808080u;
+                }
             }
-            if (c0 + r < nb) {
-                const int8_t* p = b + (c0 + r) * ldb + byte0;
-                vb = (ALIGNED && valid == 4) ? *reinterpret_cast<const uint32_t*>(p) : load_bytes4(p, valid);
-            }
-            sa[r][k] = va ^ 0x80808080u;  // signed -> unsigned order, |x - y| unchanged
-            sb[r][k] = vb ^ 0x80808080u;
         }
         __syncthreads();
+#pragma unroll 2
         for (int k = 0; k < kn; ++k) {
-            uint32_t av[4], bv[4];
+            uint32_t av[8], bv[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = sa[ty * 4 + i][k];
+            for (int i = 0; i < 8; ++i) av[i] = sa[ty * 8 + i][k];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = sb[tx + 16 * j][k];
+            for (int j = 0; j < 8; ++j) bv[j] = sb[j * 16 + tx][k];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_sad_u8(av[i], bv[j], acc[i][j]);
+                for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_sad_u8(av[i], bv[j], acc[i][j]);
         }
     }
+    const int64_t c = c0 + tx * 8;
+    const bool wide = c + 8 <= nb && (ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t r = r0 + ty * 4 + i;
+    for (int i = 0; i < 8; ++i) {
+        const int64_t r = r0 + ty * 8 + i;
         if (r >= na) continue;
+        int32_t* __restrict__ o = out + r * ldo + c;
+        if (wide) {
+            typedef int32_t v4i32 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<v4i32*>(o) = (v4i32){(int32_t)acc[i][0], (int32_t)acc[i][1], (int32_t)acc[i][2], (int32_t)acc[i][3]};
+            *reinterpret_cast<v4i32*>(o + 4) = (v4i32){(int32_t)acc[i][4], (int32_t)acc[i][5], (int32_t)acc[i][6], (int32_t)acc[i][7]};
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t c = c0 + tx + 16 * j;
-            if (c < nb) out[r * ldo + c] = (int32_t)acc[i][j];
+            for (int j = 0; j < 8; ++j)
+                if (c + j < nb) o[j] = (int32_t)acc[i][j];
         }
     }
 }

@@ -17,7 +17,10 @@ FIX = os.path.join(gu.GOLD, 'ref_fixtures')
 def test_l1_matrix_exact():
     from dctdomain_amd.similarity import l1_matrix
     rng = np.random.default_rng(0)
-    for na, nb, d in ((1, 1, 480), (43, 43, 480), (130, 77, 460), (5, 200, 255), (64, 65, 7), (3, 3, 1027)):
+    # (the kernel works on 128 x 128 tiles, 32 dwords of the fingerprints at a time: shapes around those edges, columns that
+    #  end inside a thread's eight -> the narrow store path, a width past four chunks)
+    for na, nb, d in ((1, 1, 480), (43, 43, 480), (130, 77, 460), (5, 200, 255), (64, 65, 7), (3, 3, 1027),
+                      (128, 128, 480), (129, 257, 480), (300, 391, 128), (257, 130, 129), (1000, 517, 480)):
         a = rng.integers(0, 128, size=(na, d)).astype(np.int8)
         b = rng.integers(-128, 128, size=(nb, d)).astype(np.int8)
         exp = np.abs(a.astype(np.int64)[:, None, :] - b.astype(np.int64)[None, :, :]).sum(-1)
