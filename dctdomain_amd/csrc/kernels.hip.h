@@ -1025,9 +1025,6 @@ struct Run {
 #ifndef DCTFP_WALK_MIN_WAVES
 #define DCTFP_WALK_MIN_WAVES 4       // waves per SIMD the register allocation is held to (4 -> 128 VGPRs)
 #endif
-#ifndef DCTFP_WALK_ONE_TAIL
-#define DCTFP_WALK_ONE_TAIL 1        // the rows a piece leaves after its full groups: 1 = one round of loads, 0 = a group of 4, then 1-3
-#endif
 #ifndef DCTFP_WALK_B_DEPTH
 #define DCTFP_WALK_B_DEPTH 0         // k-steps of stage-B fragments in flight during a flush: 0 = by shape (below), else 1, 2, 4
 #endif
@@ -1301,20 +1298,6 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
 #pragma unroll
                         for (int u = 0; u < UNROLL; ++u) row_update(xv[u], r + u);
                     }
-#if DCTFP_WALK_ONE_TAIL
-                    // what is left of the piece (1 .. UNROLL - 1 rows) in ONE round of loads: a round costs a memory latency
-                    // whatever it carries, and a piece of ~90 rows paid for 1.25 extra rounds on average (a group of 4, then 1-3)
-                    if (r < piece.n_rows) {
-                        constexpr int TAIL = UNROLL - 1;
-                        Rw xv[TAIL];
-#pragma unroll
-                        for (int u = 0; u < TAIL; ++u)
-                            if (r + u < piece.n_rows) xv[u] = load_row(r + u);
-#pragma unroll
-                        for (int u = 0; u < TAIL; ++u)
-                            if (r + u < piece.n_rows) row_update(xv[u], r + u);
-                    }
-#else
                     if constexpr (UNROLL > 4) {  // what is left of the piece: groups of 4 (one at most up to 8 rows in flight) ...
                         for (int g4 = 0; g4 < (UNROLL - 1) / 4; ++g4) {
                             if (r + 4 > piece.n_rows) break;
@@ -1335,7 +1318,6 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                         for (int u = 0; u < 3; ++u)
                             if (r + u < piece.n_rows) row_update(xv[u], r + u);
                     }
-#endif
                     if constexpr (HW) {  // prefix sums past this piece's last and at its first row
                         const CosTab wpre = wtp + (size_t)w_rows * NK;
 #pragma unroll
