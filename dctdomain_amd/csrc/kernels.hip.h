@@ -1069,6 +1069,11 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Ten waves on four SIMDs sit 3-3-2-2, and a SIMD issues its oldest wave first: the youngest wave of a three-wave SIMD falls
+    // behind, and at every flush the other nine wait for it (tools/wave_wait_probe.py: waves 0-3 spent 24 % of their time at
+    // that barrier, 4-7 16 %, 8-9 0.5 %; a fixed higher priority for the later waves only moved the role to waves 0 and 1).
+    // The three waves w, w + 4, w + 8 of a SIMD therefore take turns at the issue priority, job by job: c4 +0.9 %.
+    uint32_t prio_turn = (uint32_t)wave >> 2;
     const Run run = runs[blockIdx.x];
     // A wave owns 128 channel pairs (d, D-1-d): lanes 0..31 stream channels [128 w, 128 w + 128), lanes 32..63 their mirror
     // images -- two 512-byte segments of every row (as fast as one of 1 KiB: tools/microbench/read_ceiling.hip) -- so that
@@ -1124,6 +1129,13 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
 
         for (uint32_t part = 0; part < n_walk_jobs; ++part) {
             double f[NK][VEC];
+            if constexpr (S >= 10) {
+                const uint32_t turn = prio_turn % 3u;
+                if (turn == 0) __builtin_amdgcn_s_setprio(0);
+                else if (turn == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(2);
+                ++prio_turn;
+            }
             DCTFP_TL_MARK(6);
             DCTFP_TL_COUNT(9);
             if (part < wk.n_parts) {
@@ -1548,7 +1560,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
             trace[4 * idx + 0] = tl_begin;
             trace[4 * idx + 1] = tl_prev;
             trace[4 * idx + 2] = ((unsigned long long)xcc << 32) | hw;
-            trace[4 * idx + 3] = ((unsigned long long)blockIdx.x << 32) | (unsigned)wave;
+            trace[4 * idx + 3] = ((unsigned long long)tl_acc[3] << 32) | ((unsigned long long)(blockIdx.x & 0xffffffu) << 8) | (unsigned)wave;  // barrier wait (ticks), workgroup, wave
         }
     }
 #endif
