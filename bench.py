@@ -21,6 +21,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# a fatal error names itself in this run's stderr (glibc's heap / stack messages otherwise go to /dev/tty; libdctfp.so
+# prints the native frames of a SIGABRT / SIGSEGV): see tests/conftest.py
+os.environ.setdefault('LIBC_FATAL_STDERR_', '1')
+os.environ.setdefault('PYTHONFAULTHANDLER', '1')
+os.environ.setdefault('DCTFP_CRASH_BACKTRACE', '1')
+
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -154,6 +160,9 @@ def main():
     ddist.init(args.backend, device)   # "nccl" is RCCL on ROCm; used for the barrier + max-over-ranks only
 
     ctx = dd.get_context(dev_index)
+    if rank == 0:       # stderr: which HIP / HSA runtime files the kernels run on (stdout carries the one JSON line)
+        from dctdomain_amd import _lib as _ddlib
+        print(_ddlib.runtime_report(), file=sys.stderr, flush=True)
     for kv in args.opt:
         k, v = kv.split('=')
         ctx.set_option(k, int(v))

@@ -5,9 +5,11 @@ library to exist already."""
 
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
+import tempfile
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.join(ROOT, 'dctdomain_amd')
@@ -47,17 +49,34 @@ def _library_commands(force: bool):
     return out
 
 
+def sha256_of(path: str) -> str:
+    with open(path, 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -> dctdomain_amd/libdctfp.so (+ libdctfp_experiments.so), the two compilations side by
-    side.  Returns the path of the product library."""
+    side, EACH IN ITS OWN SCRATCH DIRECTORY: hipcc leaves intermediates named after the source
+    (<src>-hip-amdgcn-amd-amdhsa.hipfb, seen on the GPU box) in its working directory, and two compilations of the same
+    dctfp.hip in one directory could hand each other's device code to the link step.  Prints the sha256 of what it built.
+    Returns the path of the product library."""
     procs = []
     for target, cmd in _library_commands(force):
         if verbose:
             print(' '.join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, proc in procs:
-        if proc.wait() != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        scratch = tempfile.mkdtemp(prefix='dctfp_build_')
+        env = dict(os.environ, TMPDIR=scratch)
+        procs.append((target, cmd, scratch, subprocess.Popen(cmd, cwd=scratch, env=env)))
+    failed = None
+    for target, cmd, scratch, proc in procs:
+        rc = proc.wait()
+        shutil.rmtree(scratch, ignore_errors=True)
+        if rc != 0 and failed is None:
+            failed = subprocess.CalledProcessError(rc, cmd)
+    if failed is not None:
+        raise failed
+    for target, _, _, _ in procs:
+        print(f'sha256 {sha256_of(target)}  {os.path.relpath(target, ROOT)}')
     return LIB_PATH
 
 

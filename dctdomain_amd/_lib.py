@@ -54,7 +54,7 @@ _lib_lock = threading.Lock()
 EXPORTS = ('dctfp_version', 'dctfp_last_error', 'dctfp_create', 'dctfp_destroy', 'dctfp_quantize',
            'dctfp_idct_quant', 'dctfp_scale', 'dctfp_gather_rows', 'dctfp_contact_topk',
            'dctfp_contact_count', 'dctfp_stitch', 'dctfp_l1_matrix', 'dctfp_block_min', 'dctfp_row_select', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile', 'dctfp_host_device_pointer',
-           'dctfp_stream_synchronize')
+           'dctfp_stream_synchronize', 'dctfp_runtime_info', 'dctfp_crash_handler')
 
 
 def load(path: str = None):
@@ -76,7 +76,55 @@ def load(path: str = None):
         # process with two HSA runtimes (the second one then sees "no ROCm-capable device").
         import torch  # noqa: F401
         _lib = _configure(C.CDLL(LIB_PATH))
+        _check_single_runtime()
         return _lib
+
+
+def mapped_runtimes():
+    """{'libamdhip64': [files], 'libhsa-runtime64': [files], 'libamd_comgr': [files]} mapped into this process
+    (/proc/self/maps; no HIP call, so it is safe in a process that must not touch the GPU)."""
+    found = {'libamdhip64': [], 'libhsa-runtime64': [], 'libamd_comgr': []}
+    try:
+        with open('/proc/self/maps') as f:
+            for line in f:
+                i = line.find('/')
+                if i < 0:
+                    continue
+                path = line[i:].strip()
+                for name, paths in found.items():
+                    if name in os.path.basename(path) and path not in paths:
+                        paths.append(path)
+    except OSError:
+        pass
+    return found
+
+
+def _check_single_runtime():
+    """libdctfp.so is compiled by /opt/rocm's hipcc (ROCm 7.2) and bound -- on purpose -- to the HIP runtime of the process
+    that hands it device pointers and streams: torch's bundled libamdhip64 (ROCm 7.0; same SONAME libamdhip64.so.7, which is
+    why `import torch` comes first in load()).  A second copy of the runtime in the process would own no device memory of
+    ours and no stream of torch's: refuse to run like that instead of failing later in some launch."""
+    hip = mapped_runtimes()['libamdhip64']
+    if len(hip) > 1 and os.environ.get('DCTFP_ALLOW_RUNTIME_MIX') != '1':
+        raise ImportError('two HIP runtimes are mapped into this process: ' + ', '.join(hip) + '. libdctfp.so must share the '
+                          'runtime of the torch that owns its tensors (import torch before anything that loads /opt/rocm\'s '
+                          'libamdhip64; DCTFP_ALLOW_RUNTIME_MIX=1 overrides)')
+
+
+def runtime_report(lib=None) -> str:
+    """The text of ``dctfp_runtime_info`` (include/dctfp.h) + the sha256 of the libraries in use: printed in the header of the
+    GPU test suite, by ``__graft_entry__.smoke()`` and by ``bench.py``, so that every GPU log says which HIP / HSA runtime
+    files the hipcc-7.2-built kernels actually ran on.  Calls the HIP runtime (GPU processes only)."""
+    import hashlib
+    lib = lib if lib is not None else load()
+    buf = C.create_string_buffer(8192)
+    n = lib.dctfp_runtime_info(buf, len(buf))
+    lines = [buf.value.decode('utf-8', 'replace').rstrip(), f'distinct libamdhip64 mapped: {n}']
+    for path in (LIB_PATH, EXPERIMENTS_LIB_PATH, RECCUT_LIB_PATH):
+        if os.path.exists(path):
+            with open(path, 'rb') as f:
+                lines.append(f'sha256 {hashlib.sha256(f.read()).hexdigest()}  {os.path.basename(path)}')
+    return '\n'.join(lines)
 
 
 def _configure(lib):
@@ -108,6 +156,8 @@ def _configure(lib):
         lib.dctfp_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         lib.dctfp_host_device_pointer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         lib.dctfp_stream_synchronize.argtypes = [C.c_void_p]
+        lib.dctfp_runtime_info.argtypes = [C.c_char_p, C.c_int64]
+        lib.dctfp_crash_handler.argtypes = [C.c_int]
         for fn in EXPORTS:
             if fn not in ('dctfp_last_error', 'dctfp_contact_count'):
                 getattr(lib, fn).restype = C.c_int

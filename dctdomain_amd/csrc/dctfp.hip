@@ -6,6 +6,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -26,17 +31,20 @@ using namespace dctfp;
 
 namespace {
 
-thread_local std::string g_err;
+// Message of the calling thread's last failure.  A fixed buffer: reporting an out-of-memory condition must not allocate.
+thread_local char g_err[512] = "";
+
+void set_err(const char* msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+}
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int fail(int code, const char* fmt, ...) {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
-    g_err = buf;
     return code;
 }
 
@@ -175,23 +183,23 @@ struct dctfp_ctx {
     std::mutex mu;                              // one host thread at a time inside a context
     int ensure_copy() {
         if (copy) return DCTFP_OK;
-        if (hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) { copy = nullptr; g_err = "hipStreamCreate(copy) failed"; return DCTFP_ERR_HIP; }
+        if (hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) != hipSuccess) { copy = nullptr; set_err("hipStreamCreate(copy) failed"); return DCTFP_ERR_HIP; }
         if (hipEventCreateWithFlags(&ev_tab_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_ws_free, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_basis, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_tab_free[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_tab_free[1], hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; return DCTFP_ERR_HIP; }
+            hipEventCreateWithFlags(&ev_tab_free[1], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); return DCTFP_ERR_HIP; }
         return DCTFP_OK;
     }
     hipEvent_t ev_a[kMaxSlots] = {}, ev_b[kMaxSlots] = {};
     int ensure_side() {
         if (side) return DCTFP_OK;
         hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
-        if (e != hipSuccess) { side = nullptr; g_err = std::string("hipStreamCreate: ") + hipGetErrorString(e); return DCTFP_ERR_HIP; }
+        if (e != hipSuccess) { side = nullptr; snprintf(g_err, sizeof g_err, "hipStreamCreate: %s", hipGetErrorString(e)); return DCTFP_ERR_HIP; }
         for (int i = 0; i < kMaxSlots; ++i) {
             if (hipEventCreateWithFlags(&ev_a[i], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&ev_b[i], hipEventDisableTiming) != hipSuccess) {
-                g_err = "hipEventCreate failed";
+                set_err("hipEventCreate failed");
                 return DCTFP_ERR_HIP;
             }
         }
@@ -301,12 +309,20 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
     StEntry e;
     e.ldy = ldy;
     e.cp = cp;
+    // (an exception between here and the insertion into the cache -- std::bad_alloc from one of the host vectors below --
+    //  must not leave the device allocations behind: found by the allocation-failure hook of tests/asan/driver.cpp)
+    struct DevGuard {
+        StEntry& e;
+        bool armed = true;
+        ~DevGuard() {
+            if (!armed) return;
+            if (e.dev) (void)hipFree(e.dev);
+            if (e.frag) (void)hipFree(e.frag);
+        }
+    } dev_guard{e};
     HIP_TRY(hipMalloc((void**)&e.dev, host.size() * sizeof(double)));
     hipError_t err = hipMemcpy(e.dev, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice);
-    if (err != hipSuccess) {
-        (void)hipFree(e.dev);
-        return fail(DCTFP_ERR_HIP, "hipMemcpy(St): %s", hipGetErrorString(err));
-    }
+    if (err != hipSuccess) return fail(DCTFP_ERR_HIP, "hipMemcpy(St): %s", hipGetErrorString(err));
     if (cp == 80 && n_cols % 4 == 0) {
         // walk_ab_kernel contracts the even and the odd half of the basis apart (kernels.hip.h, "flush"):
         //   E[d][c] = sum over even k, O[d][c] = sum over odd k of cos_m(k, c) cos_D(k, d),  d < D/2, c < ceil(m/2)
@@ -340,14 +356,11 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
                     }
         err = hipMalloc((void**)&e.frag, fr.size() * sizeof(double));
         if (err == hipSuccess) err = hipMemcpy(e.frag, fr.data(), fr.size() * sizeof(double), hipMemcpyHostToDevice);
-        if (err != hipSuccess) {
-            (void)hipFree(e.dev);
-            if (e.frag) (void)hipFree(e.frag);
-            return fail(DCTFP_ERR_HIP, "St fragments: %s", hipGetErrorString(err));
-        }
+        if (err != hipSuccess) return fail(DCTFP_ERR_HIP, "St fragments: %s", hipGetErrorString(err));
     }
     e.last_use = ++ctx->tick;
     auto ins = ctx->st_cache.emplace(key, e);
+    dev_guard.armed = false;
     *out = &ins.first->second;
     return DCTFP_OK;
 }
@@ -398,8 +411,17 @@ int basis_lookup(dctfp_ctx* ctx, uint32_t len, int nk, double** out, std::vector
     return DCTFP_OK;
 }
 
+// All of `fresh` or none of it: an insertion that fails half way (std::bad_alloc) takes the entries already made back out,
+// because the caller's BasisRollback then gives their room in the arena back -- a cached length whose table has been
+// freed would hand a dangling pointer to every later call (found by the allocation-failure hook of tests/asan/driver.cpp).
 void basis_publish(dctfp_ctx* ctx, const std::vector<BasisJob>& fresh, int nk) {
-    for (const BasisJob& bj : fresh) ctx->basis_tabs.emplace(((uint64_t)nk << 32) | bj.len, bj.tab);
+    size_t done = 0;
+    try {
+        for (; done < fresh.size(); ++done) ctx->basis_tabs.emplace(((uint64_t)nk << 32) | fresh[done].len, fresh[done].tab);
+    } catch (...) {
+        for (size_t i = 0; i < done; ++i) ctx->basis_tabs.erase(((uint64_t)nk << 32) | fresh[i].len);
+        throw;
+    }
 }
 
 // State of the arena before a call reserves room for fresh tables; restore() undoes the reservations.
@@ -591,19 +613,24 @@ void launch_walk_impl(const WParams& p, bool fused, bool mfma_a = false) {
 
 template <int S, int G>
 int launch_walk_u(const WParams& p, int unroll, bool fused, bool mfma_a) {
+#ifdef DCTFP_EXPERIMENTS
+    // rows in flight other than 8: A/B builds only (option ab_unroll, which libdctfp.so does not know)
     if (unroll == 4) launch_walk_impl<float, S, G, 5, 4>(p, fused);
     else if (unroll == 6) launch_walk_impl<float, S, G, 5, 6>(p, fused);
-#ifdef DCTFP_EXPERIMENTS
     else if (unroll == 12 && G == 4) launch_walk_impl<float, S, 4, 5, 12>(p, fused);
     else if (unroll == 16 && G == 4) launch_walk_impl<float, S, 4, 5, 16>(p, fused);
+    else
+#else
+    (void)unroll;
 #endif
-    else launch_walk_impl<float, S, G, 5, 8>(p, fused, mfma_a);
+    launch_walk_impl<float, S, G, 5, 8>(p, fused, mfma_a);
     return DCTFP_OK;
 }
 
-// Instantiated shapes: S waves cover up to 256 S channels; G = jobs per flush <= 4 (the rows of an MFMA tile), bounded by
-// the LDS too (2304 B per wave and job: G = 4 leaves room for 17 waves per CU, G = 3 for 23).  A flush costs the same
-// MFMAs for 1..4 jobs, so G = 4 is the default everywhere.  Half-precision rows: the default shape only.
+// Instantiated shapes: S waves cover up to 256 S channels; G = jobs per flush = 4, the rows of an MFMA tile (a flush costs
+// the same MFMAs for 1..4 jobs; the LDS -- 2304 B per wave and job -- leaves room for 17 waves per CU).  G = 3 and other
+// numbers of rows in flight exist in libdctfp_experiments.so only (options ab_group / ab_unroll): the product library holds
+// the 3 widths x {plain, fused} x {float32, float16, bfloat16} = 18 builds it can reach.
 int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fused, bool mfma_a) {
     if (dtype == DCTFP_F16 || dtype == DCTFP_BF16) {
         const bool h = dtype == DCTFP_F16;
@@ -613,11 +640,13 @@ int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fuse
         return DCTFP_OK;
     }
     if (s == 3 && g == 4) return launch_walk_u<3, 4>(p, unroll, fused, mfma_a);
-    if (s == 3 && g == 3) return launch_walk_u<3, 3>(p, unroll, fused, mfma_a);
     if (s == 5 && g == 4) return launch_walk_u<5, 4>(p, unroll, fused, mfma_a);
-    if (s == 5 && g == 3) return launch_walk_u<5, 3>(p, unroll, fused, mfma_a);
     if (s == 10 && g == 4) return launch_walk_u<10, 4>(p, unroll, fused, mfma_a);
+#ifdef DCTFP_EXPERIMENTS
+    if (s == 3 && g == 3) return launch_walk_u<3, 3>(p, unroll, fused, mfma_a);
+    if (s == 5 && g == 3) return launch_walk_u<5, 3>(p, unroll, fused, mfma_a);
     if (s == 10 && g == 3) return launch_walk_u<10, 3>(p, unroll, fused, mfma_a);
+#endif
     return fail(DCTFP_ERR_INVALID, "walk kernel: no build for %d waves x %d jobs per flush", s, g);
 }
 
@@ -645,15 +674,31 @@ int prof_end(EventPair* ep, hipStream_t s) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Nothing may throw across the C ABI: an exception that leaves an extern "C" function ends the process in std::terminate
+// (SIGABRT on the calling thread).  Every entry point is a function-try-block that ends here; the vectors of the table
+// build are the only things that can throw (std::bad_alloc, std::length_error).
+int guard_exception(const char* where) noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        return fail(DCTFP_ERR_NOMEM, "%s: out of host memory", where);
+    } catch (const std::exception& e) {
+        return fail(DCTFP_ERR_INVALID, "%s: %s", where, e.what());
+    } catch (...) {
+        return fail(DCTFP_ERR_INVALID, "%s: unknown C++ exception", where);
+    }
+}
+#define DCTFP_GUARD(name) catch (...) { return guard_exception(name); }
+
 }  // namespace
 
 extern "C" {
 
 int dctfp_version(void) { return DCTFP_VERSION; }
 
-const char* dctfp_last_error(void) { return g_err.c_str(); }
+const char* dctfp_last_error(void) { return g_err; }
 
-int dctfp_create(int device, dctfp_ctx** out) {
+int dctfp_create(int device, dctfp_ctx** out) try {
     if (!out) return fail(DCTFP_ERR_INVALID, "dctfp_create: out is NULL");
     *out = nullptr;
     int count = 0;
@@ -687,9 +732,9 @@ int dctfp_create(int device, dctfp_ctx** out) {
     }
     *out = ctx;
     return DCTFP_OK;
-}
+} DCTFP_GUARD("dctfp_create")
 
-int dctfp_destroy(dctfp_ctx* ctx) {
+int dctfp_destroy(dctfp_ctx* ctx) try {
     if (!ctx) return DCTFP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
@@ -726,9 +771,9 @@ int dctfp_destroy(dctfp_ctx* ctx) {
     }
     delete ctx;
     return DCTFP_OK;
-}
+} DCTFP_GUARD("dctfp_destroy")
 
-int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
+int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) try {
     if (!ctx || !name) return fail(DCTFP_ERR_INVALID, "dctfp_set_option: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     std::string n(name);
@@ -818,9 +863,9 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) {
         return fail(DCTFP_ERR_INVALID, "unknown option '%s'", name);
     }
     return DCTFP_OK;
-}
+} DCTFP_GUARD("dctfp_set_option")
 
-int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
+int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) try {
     if (!ctx || !name || !value) return fail(DCTFP_ERR_INVALID, "dctfp_get_option: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     std::string n(name);
@@ -837,8 +882,8 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
         HIP_TRY(hipMemcpy(&v, ctx->degenerate, sizeof v, hipMemcpyDeviceToHost));
         *value = (int64_t)v;
     } else if (n == "degenerate_seen") {  // no device synchronisation: meaningful once the caller has waited for its call
-        *value = *(volatile uint32_t*)ctx->flag_host ? 1 : 0;
-        *(volatile uint32_t*)ctx->flag_host = 0;
+        // one exchange: a kernel of another stream that raises the flag between a read and a clear would be lost
+        *value = __atomic_exchange_n(ctx->flag_host, 0u, __ATOMIC_ACQ_REL) ? 1 : 0;
     }
 #ifdef DCTFP_EXPERIMENTS
     else if (n == "stage_b") *value = ctx->opt_stage_b;
@@ -879,9 +924,9 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) {
 #endif
     else return fail(DCTFP_ERR_INVALID, "unknown option '%s'", name);
     return DCTFP_OK;
-}
+} DCTFP_GUARD("dctfp_get_option")
 
-int dctfp_profile(dctfp_ctx* ctx, double ms[2], int64_t launches[2]) {
+int dctfp_profile(dctfp_ctx* ctx, double ms[2], int64_t launches[2]) try {
     if (!ctx || !ms || !launches) return fail(DCTFP_ERR_INVALID, "dctfp_profile: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
@@ -901,7 +946,7 @@ int dctfp_profile(dctfp_ctx* ctx, double ms[2], int64_t launches[2]) {
         ctx->prof_n[i] = 0;
     }
     return DCTFP_OK;
-}
+} DCTFP_GUARD("dctfp_profile")
 
 }  // extern "C"
 
@@ -1584,7 +1629,7 @@ extern "C" {
 
 int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, int32_t n_seq,
                    const int64_t* seq_rows, const dctfp_piece* pieces, int64_t n_pieces, int64_t n_domains,
-                   int8_t* out, int64_t out_stride, void* stream_v) {
+                   int8_t* out, int64_t out_stride, void* stream_v) try {
     if (!ctx) return fail(DCTFP_ERR_INVALID, "dctfp_quantize: ctx is NULL");
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (n_layers < 0 || n_seq < 0 || n_pieces < 0 || n_domains < 0)
@@ -1634,10 +1679,10 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
         }
     }
     return quantize_impl(ctx, layers, n_layers, n_seq, seq_rows, pieces, n_pieces, n_domains, out, out_stride, stream, nullptr);
-}
+} DCTFP_GUARD("dctfp_quantize")
 
 int dctfp_idct_quant(dctfp_ctx* ctx, const void* vec, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
-                     int32_t num, double* scaled_out, double* coef_out, void* stream_v) {
+                     int32_t num, double* scaled_out, double* coef_out, void* stream_v) try {
     if (!ctx || !vec) return fail(DCTFP_ERR_INVALID, "dctfp_idct_quant: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (dtype != DCTFP_F32 && dtype != DCTFP_F64) return fail(DCTFP_ERR_INVALID, "dctfp_idct_quant: dtype %d", dtype);
@@ -1660,9 +1705,9 @@ int dctfp_idct_quant(dctfp_ctx* ctx, const void* vec, int32_t dtype, int64_t n_r
         HIP_TRY(hipGetLastError());
     }
     return DCTFP_OK;
-}
+} DCTFP_GUARD("dctfp_idct_quant")
 
-int dctfp_scale(dctfp_ctx* ctx, const double* vec, int64_t n, double* out, void* stream_v) {
+int dctfp_scale(dctfp_ctx* ctx, const double* vec, int64_t n, double* out, void* stream_v) try {
     if (!ctx || !vec || !out) return fail(DCTFP_ERR_INVALID, "dctfp_scale: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (n < 1) return fail(DCTFP_ERR_INVALID, "dctfp_scale: empty vector");
@@ -1670,10 +1715,10 @@ int dctfp_scale(dctfp_ctx* ctx, const double* vec, int64_t n, double* out, void*
     hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_v, vec, n, out);
     HIP_TRY(hipGetLastError());
     return DCTFP_OK;
-}
+} DCTFP_GUARD("dctfp_scale")
 
 int dctfp_gather_rows(dctfp_ctx* ctx, const void* embed, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
-                      const dctfp_piece* pieces, int64_t n_pieces, double* out, void* stream_v) {
+                      const dctfp_piece* pieces, int64_t n_pieces, double* out, void* stream_v) try {
     if (!ctx || !embed || !pieces || !out) return fail(DCTFP_ERR_INVALID, "dctfp_gather_rows: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (dtype != DCTFP_F32 && dtype != DCTFP_F64) return fail(DCTFP_ERR_INVALID, "dctfp_gather_rows: dtype %d", dtype);
@@ -1713,12 +1758,12 @@ int dctfp_gather_rows(dctfp_ctx* ctx, const void* embed, int32_t dtype, int64_t 
         hipLaunchKernelGGL((gather_rows_kernel<double>), dim3(gx, (unsigned)n_pieces), dim3(256), 0, stream, (const PieceA*)tab.p, (int)n_pieces, n_cols, ld, out);
     HIP_TRY(hipGetLastError());
     return mark_table_used(ctx, buf, stream);
-}
+} DCTFP_GUARD("dctfp_gather_rows")
 
 
 int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* ld, const int32_t* n_res,
                        int32_t n_prot, double t, int32_t* out_i, int32_t* out_j, float* out_v,
-                       const int64_t* out_offs, int32_t* out_n, void* stream_v) {
+                       const int64_t* out_offs, int32_t* out_n, void* stream_v) try {
     if (!ctx || !maps || !ld || !n_res || !out_i || !out_j || !out_v || !out_offs || !out_n)
         return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
@@ -1839,10 +1884,10 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
         HIP_TRY(hipGetLastError());
     }
     return mark_table_used(ctx, buf, stream);
-}
+} DCTFP_GUARD("dctfp_contact_topk")
 
 int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, int32_t n_cols, int32_t square,
-                 void* stream_v) {
+                 void* stream_v) try {
     if (!ctx || (!jobs && n_jobs > 0)) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (n_jobs < 0 || (!square && n_cols < 1)) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: bad count");
@@ -1905,10 +1950,10 @@ int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, i
         }
     }
     return mark_table_used(ctx, buf, stream);
-}
+} DCTFP_GUARD("dctfp_stitch")
 
 int dctfp_l1_matrix(dctfp_ctx* ctx, const int8_t* a, int64_t na, int64_t lda, const int8_t* b, int64_t nb, int64_t ldb,
-                    int32_t d, int32_t* out, int64_t ldo, void* stream_v) {
+                    int32_t d, int32_t* out, int64_t ldo, void* stream_v) try {
     if (!ctx || !a || !b || !out) return fail(DCTFP_ERR_INVALID, "dctfp_l1_matrix: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (na < 0 || nb < 0 || d < 1 || lda < d || ldb < d || ldo < nb) return fail(DCTFP_ERR_INVALID, "dctfp_l1_matrix: bad shape");
@@ -1922,10 +1967,10 @@ int dctfp_l1_matrix(dctfp_ctx* ctx, const int8_t* a, int64_t na, int64_t lda, co
     else hipLaunchKernelGGL((l1_matrix_kernel<false>), grid, dim3(256), 0, stream, a, na, lda, b, nb, ldb, d, out, ldo);
     HIP_TRY(hipGetLastError());
     return DCTFP_OK;
-}
+} DCTFP_GUARD("dctfp_l1_matrix")
 
 int dctfp_block_min(dctfp_ctx* ctx, const int32_t* dist, int64_t ldo, const int64_t* idx_a, int64_t npa,
-                    const int64_t* idx_b, int64_t npb, int32_t* out_min, int32_t* out_last, void* stream_v) {
+                    const int64_t* idx_b, int64_t npb, int32_t* out_min, int32_t* out_last, void* stream_v) try {
     if (!ctx || !dist || !idx_a || !idx_b || !out_min || !out_last) return fail(DCTFP_ERR_INVALID, "dctfp_block_min: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (npa < 0 || npb < 0) return fail(DCTFP_ERR_INVALID, "dctfp_block_min: negative count");
@@ -1936,10 +1981,10 @@ int dctfp_block_min(dctfp_ctx* ctx, const int32_t* dist, int64_t ldo, const int6
                        idx_a, npa, idx_b, npb, out_min, out_last);
     HIP_TRY(hipGetLastError());
     return DCTFP_OK;
-}
+} DCTFP_GUARD("dctfp_block_min")
 
 int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k,
-                     int32_t* out_val, int32_t* out_idx, void* stream_v) {
+                     int32_t* out_val, int32_t* out_idx, void* stream_v) try {
     if (!ctx || !dist || !out_val || !out_idx) return fail(DCTFP_ERR_INVALID, "dctfp_row_select: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (n_rows < 0 || n_cols < 1 || ld < n_cols || k < 1 || k > n_cols) return fail(DCTFP_ERR_INVALID, "dctfp_row_select: bad shape");
@@ -1950,9 +1995,9 @@ int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_
                        out_val, out_idx);
     HIP_TRY(hipGetLastError());
     return DCTFP_OK;
-}
+} DCTFP_GUARD("dctfp_row_select")
 
-int dctfp_host_device_pointer(void* host, void** dev) {
+int dctfp_host_device_pointer(void* host, void** dev) try {
     if (!host || !dev) return fail(DCTFP_ERR_INVALID, "dctfp_host_device_pointer: NULL argument");
     *dev = nullptr;
     hipError_t e = hipHostGetDevicePointer(dev, host, 0);
@@ -1962,12 +2007,12 @@ int dctfp_host_device_pointer(void* host, void** dev) {
         return fail(DCTFP_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
     }
     return DCTFP_OK;
-}
+} DCTFP_GUARD("dctfp_host_device_pointer")
 
-int dctfp_stream_synchronize(void* stream) {
+int dctfp_stream_synchronize(void* stream) try {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return DCTFP_OK;
-}
+} DCTFP_GUARD("dctfp_stream_synchronize")
 
 int64_t dctfp_contact_count(int32_t n_res, double t) {
     if (n_res < 6) return 0;
@@ -1977,4 +2022,118 @@ int64_t dctfp_contact_count(int32_t n_res, double t) {
     return tot > cand ? cand : tot;
 }
 
+
+// ---- diagnostics: which HIP / HSA runtime this library is bound to, and a crash handler that names the failing frame ----
+
+/* Writes one line per fact into buf: the HIP version this library was compiled against, the version of the runtime it is
+ * bound to in this process (hipRuntimeGetVersion / hipDriverGetVersion), the file that runtime was loaded from (dladdr of
+ * hipMalloc) and every libamdhip64 / libhsa-runtime64 / libamd_comgr mapped into the process (/proc/self/maps).
+ * libdctfp.so is compiled by /opt/rocm's hipcc but must run on the runtime of the process that owns the device pointers
+ * and streams it is given (torch's bundled one): exactly one of each may be mapped.  Returns the number of distinct
+ * libamdhip64 files mapped (1 = healthy) or a negative error. */
+int dctfp_runtime_info(char* buf, int64_t cap) try {
+    if (!buf || cap < 64) return fail(DCTFP_ERR_INVALID, "dctfp_runtime_info: buffer of at least 64 bytes");
+    size_t used = 0;
+    auto put = [&](const char* fmt, ...) {
+        if (used + 1 >= (size_t)cap) return;
+        va_list ap;
+        va_start(ap, fmt);
+        const int n = vsnprintf(buf + used, (size_t)cap - used, fmt, ap);
+        va_end(ap);
+        if (n > 0) used = std::min((size_t)cap - 1, used + (size_t)n);
+    };
+    int rt = 0, drv = 0;
+    const hipError_t e1 = hipRuntimeGetVersion(&rt), e2 = hipDriverGetVersion(&drv);
+    put("libdctfp compiled against HIP %d.%d.%d; bound runtime reports hipRuntimeGetVersion=%d (%s) hipDriverGetVersion=%d (%s)\n",
+        HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH, rt, hipGetErrorName(e1), drv, hipGetErrorName(e2));
+    Dl_info info;
+    if (dladdr((void*)&hipRuntimeGetVersion, &info) && info.dli_fname) put("hipRuntimeGetVersion resolves into %s\n", info.dli_fname);
+    if (dladdr((void*)&dctfp_runtime_info, &info) && info.dli_fname) put("this library: %s\n", info.dli_fname);
+    std::vector<std::string> seen;
+    int n_hip = 0;
+    if (FILE* f = fopen("/proc/self/maps", "r")) {
+        char line[1024];
+        while (fgets(line, sizeof line, f)) {
+            const char* path = strchr(line, '/');
+            if (!path) continue;
+            if (!strstr(path, "libamdhip64") && !strstr(path, "libhsa-runtime64") && !strstr(path, "libamd_comgr")) continue;
+            std::string ps(path);
+            while (!ps.empty() && (ps.back() == '\n' || ps.back() == ' ')) ps.pop_back();
+            if (std::find(seen.begin(), seen.end(), ps) != seen.end()) continue;
+            seen.push_back(ps);
+            if (ps.find("libamdhip64") != std::string::npos) ++n_hip;
+            put("mapped: %s\n", ps.c_str());
+        }
+        fclose(f);
+    }
+    return n_hip;
+} DCTFP_GUARD("dctfp_runtime_info")
+
+namespace {
+struct sigaction g_prev_abrt, g_prev_segv, g_prev_bus;
+bool g_crash_installed = false;
+
+// SIGABRT / SIGSEGV / SIGBUS: the native frames to stderr (backtrace_symbols_fd does not allocate), then the handler that was
+// installed before (Python's faulthandler prints the Python stack and re-raises), so an abort names itself in the log of the
+// ordinary run instead of needing a second one under a debugger.
+void crash_handler(int sig, siginfo_t* si, void* uc) {
+    static const char head[] = "\n*** libdctfp: fatal signal; native backtrace of the failing thread:\n";
+    (void)!write(2, head, sizeof head - 1);
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    static const char tail[] = "*** end of native backtrace\n";
+    (void)!write(2, tail, sizeof tail - 1);
+    struct sigaction* prev = sig == SIGABRT ? &g_prev_abrt : (sig == SIGSEGV ? &g_prev_segv : &g_prev_bus);
+    sigaction(sig, prev, nullptr);
+    if ((prev->sa_flags & SA_SIGINFO) && prev->sa_sigaction) {
+        prev->sa_sigaction(sig, si, uc);
+    } else if (prev->sa_handler != SIG_DFL && prev->sa_handler != SIG_IGN && prev->sa_handler) {
+        prev->sa_handler(sig);
+    }
+    raise(sig);  // (back under the previous disposition: ends the process the way it would have ended without us)
+}
+}  // namespace
+
+/* enable = 1: install the handler above (idempotent); 0: put the previous handlers back.  Installed at load time when the
+ * environment has DCTFP_CRASH_BACKTRACE=1 (tests/conftest.py, bench.py, __graft_entry__.smoke and the tools/ wrappers set it),
+ * and always by libdctfp_experiments.so. */
+int dctfp_crash_handler(int enable) {
+    if (enable && !g_crash_installed) {
+        // (libdctfp.so and libdctfp_experiments.so may both be loaded: one handler per process)
+        if (getenv("DCTFP_CRASH_HANDLER_INSTALLED")) return DCTFP_OK;
+        setenv("DCTFP_CRASH_HANDLER_INSTALLED", "1", 1);
+        void* warm[4];
+        (void)backtrace(warm, 4);  // loads libgcc's unwinder now, not inside the handler
+        struct sigaction sa;
+        memset(&sa, 0, sizeof sa);
+        sa.sa_sigaction = crash_handler;
+        sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+        sigemptyset(&sa.sa_mask);
+        sigaction(SIGABRT, &sa, &g_prev_abrt);
+        sigaction(SIGSEGV, &sa, &g_prev_segv);
+        sigaction(SIGBUS, &sa, &g_prev_bus);
+        g_crash_installed = true;
+    } else if (!enable && g_crash_installed) {
+        sigaction(SIGABRT, &g_prev_abrt, nullptr);
+        sigaction(SIGSEGV, &g_prev_segv, nullptr);
+        sigaction(SIGBUS, &g_prev_bus, nullptr);
+        unsetenv("DCTFP_CRASH_HANDLER_INSTALLED");
+        g_crash_installed = false;
+    }
+    return DCTFP_OK;
+}
+
 }  // extern "C"
+
+namespace {
+__attribute__((constructor)) void dctfp_on_load() {
+#ifdef DCTFP_EXPERIMENTS
+    const bool on = true;
+#else
+    const char* v = getenv("DCTFP_CRASH_BACKTRACE");
+    const bool on = v && v[0] == '1';
+#endif
+    if (on) (void)dctfp_crash_handler(1);
+}
+}  // namespace

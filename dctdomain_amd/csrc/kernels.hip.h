@@ -1995,8 +1995,10 @@ __global__ __launch_bounds__(256) void stitch_contacts_kernel(const StitchJob* _
 // ---------------------------------------------------------------------------
 // Fingerprint similarity (consumers: src/dct-sim.py:12-50, src/query_db.py:57,76).
 // L1 distance matrix between two sets of int8 fingerprints with v_sad_u8 (4 bytes per
-// instruction); 64 x 64 output tile per workgroup, both operand tiles staged in LDS in
-// chunks of 512 bytes (row stride 129 dwords: conflict-free column walks).
+// instruction); 128 x 128 distances per workgroup of 256 threads, 8 x 8 per thread, both operand
+// tiles staged in LDS KC = 32 dwords (128 bytes of the fingerprints) at a time, row stride 33 dwords,
+// the b rows stored in the order the lanes read them (no bank conflict; a wave writes whole 512-byte
+// row segments of the result).
 // ---------------------------------------------------------------------------
 __device__ inline uint32_t load_bytes4(const int8_t* p, int n_valid) {  // n_valid in 1..4
     uint32_t v = 0;

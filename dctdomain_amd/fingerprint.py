@@ -205,6 +205,11 @@ class Fingerprint:
         groups = []           # (table, offset into the pinned buffer, width, first layer, last layer)
         dev = mats[0].device if mats else None
         stream = _raw_stream(dev) if mats else 0
+        ctx = _lib.get_context(dev.index if dev.index is not None else torch.cuda.current_device()) if mats else None
+        if ctx is not None:
+            # the constant-channel flag belongs to the context (include/dctfp.h): whatever an earlier caller left unread
+            # (quantize_batch users, tools) is not about THIS protein
+            ctx.get_option('degenerate_seen')
         i = 0
         while i < len(mats):
             j = i
@@ -219,8 +224,7 @@ class Fingerprint:
                 groups.append((table, (buf, off), width, i, j))
             i = j + 1
         hosts = _fetch_results(groups, stream)
-        if groups and _lib.get_context(dev.index if dev.index is not None else torch.cuda.current_device()) \
-                .get_option('degenerate_seen'):
+        if groups and ctx.get_option('degenerate_seen'):
             warn_constant_channel([self.pid])
 
         # quants[key] = the blocks of every layer, layer-major, then domain order (:184-196); a key that occurs

@@ -186,6 +186,17 @@ int dctfp_host_device_pointer(void* host, void** dev);
  * dctfp_quantize writes into its pinned result buffer. */
 int dctfp_stream_synchronize(void* stream);
 
+/* Diagnostics (no reference counterpart).
+ * dctfp_runtime_info: text into buf -- the HIP version the library was compiled against, the version and file of the HIP
+ *   runtime it is bound to in this process, and every libamdhip64 / libhsa-runtime64 / libamd_comgr file mapped.  The
+ *   library must run on the runtime that owns the device pointers and streams it is handed (the caller's torch): returns
+ *   the number of distinct libamdhip64 files mapped, 1 when healthy.
+ * dctfp_crash_handler(1): SIGABRT / SIGSEGV / SIGBUS print the native backtrace of the failing thread to stderr before the
+ *   previously installed handler (e.g. Python's faulthandler) runs; also installed at load time when the environment has
+ *   DCTFP_CRASH_BACKTRACE=1.  (0) removes it. */
+int dctfp_runtime_info(char* buf, int64_t cap);
+int dctfp_crash_handler(int enable);
+
 /* Options (no reference counterpart).
  *
  * What a user of the drop-in may want:
@@ -207,7 +218,8 @@ int dctfp_stream_synchronize(void* stream);
  *                  matched.  Reading synchronises the device; writing 0 resets the counter.
  *   "degenerate_seen"  read: 1 if a kernel has met such a channel since the last read (then cleared).  The kernels set a
  *                  word in pinned host memory, so this costs no synchronisation and no copy: it is meaningful once the
- *                  caller has waited for its call.  dctdomain_amd.Fingerprint.quantize and make_db read it after every
+ *                  caller has waited for its call.  The flag belongs to the CONTEXT, not to a call: a caller that wants to
+ *                  know about its own call reads (= clears) it before enqueueing and again after waiting.  dctdomain_amd.Fingerprint.quantize and make_db read it after every
  *                  call / flush and log a warning with the protein ids.
  *
  * Engineering knobs -- ONLY in libdctfp_experiments.so, the same sources built with -DDCTFP_EXPERIMENTS (A/B measurements

@@ -15,6 +15,42 @@
 
 extern "C" unsigned long dctfp_stub_counter(int which);
 
+// ---- allocation-failure hook: the N-th operator new from now on throws std::bad_alloc (once).  Nothing may throw across
+// the C ABI -- an exception that left dctfp_quantize would end this process in std::terminate (SIGABRT on the calling
+// thread) -- so the call has to come back with DCTFP_ERR_NOMEM (or have succeeded, if it needed fewer allocations).
+#include <new>
+static long g_fail_after = -1;   // < 0: never
+static long g_failed = 0;
+static void* hooked_alloc(size_t n, size_t align) {
+    if (g_fail_after >= 0 && g_fail_after-- == 0) {
+        ++g_failed;
+        throw std::bad_alloc();
+    }
+    void* p = align > 16 ? aligned_alloc(align, (n + align - 1) / align * align) : malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void* operator new(size_t n) { return hooked_alloc(n, 0); }
+void* operator new[](size_t n) { return hooked_alloc(n, 0); }
+void* operator new(size_t n, std::align_val_t a) { return hooked_alloc(n, (size_t)a); }
+void* operator new[](size_t n, std::align_val_t a) { return hooked_alloc(n, (size_t)a); }
+void* operator new(size_t n, const std::nothrow_t&) noexcept { try { return hooked_alloc(n, 0); } catch (...) { return nullptr; } }
+void* operator new[](size_t n, const std::nothrow_t&) noexcept { try { return hooked_alloc(n, 0); } catch (...) { return nullptr; } }
+void* operator new(size_t n, std::align_val_t a, const std::nothrow_t&) noexcept { try { return hooked_alloc(n, (size_t)a); } catch (...) { return nullptr; } }
+void* operator new[](size_t n, std::align_val_t a, const std::nothrow_t&) noexcept { try { return hooked_alloc(n, (size_t)a); } catch (...) { return nullptr; } }
+void operator delete(void* p) noexcept { free(p); }
+void operator delete[](void* p) noexcept { free(p); }
+void operator delete(void* p, size_t) noexcept { free(p); }
+void operator delete[](void* p, size_t) noexcept { free(p); }
+void operator delete(void* p, std::align_val_t) noexcept { free(p); }
+void operator delete[](void* p, std::align_val_t) noexcept { free(p); }
+void operator delete(void* p, size_t, std::align_val_t) noexcept { free(p); }
+void operator delete[](void* p, size_t, std::align_val_t) noexcept { free(p); }
+void operator delete(void* p, const std::nothrow_t&) noexcept { free(p); }
+void operator delete[](void* p, const std::nothrow_t&) noexcept { free(p); }
+void operator delete(void* p, std::align_val_t, const std::nothrow_t&) noexcept { free(p); }
+void operator delete[](void* p, std::align_val_t, const std::nothrow_t&) noexcept { free(p); }
+
 #define CHECK(expr)                                                                         \
     do {                                                                                    \
         const int rc_ = (expr);                                                             \
@@ -134,10 +170,13 @@ int main(int argc, char** argv) {
         if (uni(0, 40) == 0) CHECK(dctfp_set_option(ctx, "basis_cap_kb", 64));
         const bool inject = uni(0, 25) == 0;
         if (inject) CHECK(dctfp_set_option(ctx, "test_fail_once", 1));
-        // ---- the call (twice: the second is served from the caches)
+        // ---- the call (twice: the second is served from the caches); one call in six with a failing allocation inside
+        const bool starve = uni(0, 5) == 0;
         for (int rep = 0; rep < 2; ++rep) {
+            if (starve) g_fail_after = uni(0, rep == 0 ? 40 : 12);
             const int rc = dctfp_quantize(ctx, layers.data(), n_layers, n_seq, seq_rows.data(), pieces.data(), (int64_t)pieces.size(),
                                           n_domains, out.data(), out_stride, nullptr);
+            g_fail_after = -1;
             ++n_calls;
             if (rc == DCTFP_ERR_SHAPE || rc == DCTFP_ERR_NOMEM) { ++n_errors_expected; continue; }   // D < m / L < n / the injected failure
             if (rc != DCTFP_OK) {
@@ -154,6 +193,7 @@ int main(int argc, char** argv) {
         }
     }
     CHECK(dctfp_destroy(ctx));
+    printf("allocation failures injected and reported as DCTFP_ERR_NOMEM: %ld\n", g_failed);
     printf("asan driver: %d calls over %d rounds (%d ended in an expected error), %lu walk-kernel launches, %lu stage-A launches, "
            "%lu jobs walked by the table emulation: no memory error\n", n_calls, rounds, n_errors_expected, dctfp_stub_counter(0),
            dctfp_stub_counter(1), dctfp_stub_counter(2));

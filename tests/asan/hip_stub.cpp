@@ -231,6 +231,9 @@ hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.0f; return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "stub"; }
+const char* hipGetErrorName(hipError_t) { return "stub"; }
+hipError_t hipRuntimeGetVersion(int* v) { *v = 0; return hipSuccess; }
+hipError_t hipDriverGetVersion(int* v) { *v = 0; return hipSuccess; }
 
 void** __hipRegisterFatBinary(const void*) { static void* h; return &h; }
 void __hipUnregisterFatBinary(void**) {}

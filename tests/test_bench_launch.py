@@ -65,7 +65,11 @@ def test_traffic_stamp_matches_the_kernel_sources():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, 'profiles', 'traffic.json')) as f:
         tj = json.load(f)
-    if tj['source_sha256'] != bench.source_sha256():     # (mid-development state: visible in the summary, not a red suite)
-        pytest.xfail('profiles/traffic.json is stale: rerun tools/profile_gpu.sh + tools/collect_profiles.sh before the round ends')
+    if tj['source_sha256'] != bench.source_sha256():
+        msg = ('profiles/traffic.json is stale (the kernel sources changed after the PMC pass it holds): rerun '
+               'tools/profile_gpu.sh + tools/collect_profiles.sh -- the judged bench line would print roofline.traffic = null')
+        if os.environ.get('DCTFP_DEV_STALE_TRAFFIC_OK') == '1':      # mid-development only, asked for explicitly
+            pytest.xfail(msg)
+        pytest.fail(msg)
     for w in ('c2', 'c4', 'c5'):
         assert tj['workloads'][w]['kernel'] == 'walk_ab_kernel' and tj['workloads'][w]['hbm_bytes_per_launch'] > 0

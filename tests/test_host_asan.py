@@ -5,7 +5,8 @@ GPU AddressSanitizer is not available on the pool, and a wrong index in a job ta
 (`hipcc --cuda-host-only -fsanitize=address`), linked against a stand-in for the HIP runtime (tests/asan/hip_stub.cpp:
 device memory = host memory; a kernel launch walks the job tables the way the kernel's waves do and touches every address
 they would) and driven over a few hundred seeded random batches (tests/asan/driver.cpp): every shape class, option,
-fused-group layout, the split at giant domains, failure injection and arena restarts of the cosine-table cache."""
+fused-group layout, the split at giant domains, failure injection (also std::bad_alloc from any allocation of the table
+build: the C ABI must answer DCTFP_ERR_NOMEM, not std::terminate) and arena restarts of the cosine-table cache."""
 
 import os
 import re
@@ -66,5 +67,7 @@ def test_host_code_under_address_sanitizer(tmp_path):
         r = subprocess.run([exe, '250', str(seed)], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
         assert 'no memory error' in r.stdout
+        # std::bad_alloc inside the table build comes back as DCTFP_ERR_NOMEM through the exception barrier of the C ABI
+        assert int(re.search(r'reported as DCTFP_ERR_NOMEM: (\d+)', r.stdout).group(1)) >= 10, r.stdout
         walked = int(re.search(r'(\d+) walk-kernel launches', r.stdout).group(1))
         assert walked >= 20, r.stdout          # the production path is among what was exercised

@@ -1,4 +1,5 @@
 #!/bin/bash
+. "$(dirname "${BASH_SOURCE[0]}")/env.sh"   # LIBC_FATAL_STDERR_, PYTHONFAULTHANDLER, DCTFP_CRASH_BACKTRACE
 # A/B builds of libdctfp.so with other build-time knobs: tools/build_variant.sh NAME -DDCTFP_WALK_MIN_WAVES=3 ...
 # -> build_variants/NAME.so (git-ignored; travels with gpurun).  Use with DCTFP_LIBRARY=build_variants/NAME.so.
 set -e

@@ -1,4 +1,5 @@
 #!/bin/bash
+. "$(dirname "${BASH_SOURCE[0]}")/env.sh"   # LIBC_FATAL_STDERR_, PYTHONFAULTHANDLER, DCTFP_CRASH_BACKTRACE
 # After tools/profile_gpu.sh <round>_c2 / _c4 / _c5 ran on the GPU box: stamp profiles/traffic.json with the current
 # kernel sources and copy the summaries the documents cite into profiles/<round>/.   usage: tools/collect_profiles.sh r02
 set -e

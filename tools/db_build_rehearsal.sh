@@ -1,4 +1,5 @@
 #!/bin/bash
+. "$(dirname "${BASH_SOURCE[0]}")/env.sh"   # LIBC_FATAL_STDERR_, PYTHONFAULTHANDLER, DCTFP_CRASH_BACKTRACE
 # Scaled-down rehearsal of BASELINE config 5 (database build through the make_db drop-in) on one GPU:
 # N synthetic proteins with a pfam-like length mix -> .db / -dct.npz / .dom, synthetic language model.
 N=${1:-20000}

@@ -1,4 +1,5 @@
 #!/bin/bash
+. "$(dirname "${BASH_SOURCE[0]}")/env.sh"   # LIBC_FATAL_STDERR_, PYTHONFAULTHANDLER, DCTFP_CRASH_BACKTRACE
 # BASELINE config 5 on one GPU box: N synthetic proteins with a pfam-like length mix through the make_db drop-in
 # (synthetic language model), with the evidence the judge asked for: wall time per stage, peak RSS, file sizes, content
 # hashes -- and, in mode `two_resume`, a deliberate kill at ~50 % followed by a resumed run.

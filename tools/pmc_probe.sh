@@ -1,4 +1,5 @@
 #!/bin/bash
+. "$(dirname "${BASH_SOURCE[0]}")/env.sh"   # LIBC_FATAL_STDERR_, PYTHONFAULTHANDLER, DCTFP_CRASH_BACKTRACE
 # Runs on the GPU box (via gpurun): PMC passes of tools/path_probe.py with ONE configuration, to see what the waves of a
 # kernel spend their cycles on.  usage: tools/pmc_probe.sh <tag> <workload> <cfg>      e.g.  r02_c5_walk c5 path=2
 set -o pipefail

@@ -1,4 +1,5 @@
 #!/bin/bash
+. "$(dirname "${BASH_SOURCE[0]}")/env.sh"   # LIBC_FATAL_STDERR_, PYTHONFAULTHANDLER, DCTFP_CRASH_BACKTRACE
 # Runs tools/microbench/power_pipes.hip variant by variant and samples clocks + package power beside each (GPU box).
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/power_pipes tools/microbench/power_pipes.hip || exit 1
 for mode in read valu16 valu24 mfma; do

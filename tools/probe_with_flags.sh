@@ -1,4 +1,5 @@
 #!/bin/bash
+. "$(dirname "${BASH_SOURCE[0]}")/env.sh"   # LIBC_FATAL_STDERR_, PYTHONFAULTHANDLER, DCTFP_CRASH_BACKTRACE
 # usage: tools/probe_with_flags.sh "<hipcc flags>" <probe.py> [args]  -- run a probe against a library built with extra flags
 set -e
 flags="$1"; shift

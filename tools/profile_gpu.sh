@@ -1,4 +1,5 @@
 #!/bin/bash
+. "$(dirname "${BASH_SOURCE[0]}")/env.sh"   # LIBC_FATAL_STDERR_, PYTHONFAULTHANDLER, DCTFP_CRASH_BACKTRACE
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes of
 # bench.py, outputs under gpurun_out/prof_<tag>/.  Usage: tools/profile_gpu.sh <tag> [bench args]
 set -o pipefail

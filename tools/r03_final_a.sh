@@ -1,3 +1,4 @@
+. "$(dirname "${BASH_SOURCE[0]}")/env.sh"   # LIBC_FATAL_STDERR_, PYTHONFAULTHANDLER, DCTFP_CRASH_BACKTRACE
 # Round-3 closing run, part A: the whole GPU suite, smoke, the bench lines of every workload.
 set -x
 cd $GRAFT_REPO_ROOT

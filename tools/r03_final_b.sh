@@ -1,3 +1,4 @@
+. "$(dirname "${BASH_SOURCE[0]}")/env.sh"   # LIBC_FATAL_STDERR_, PYTHONFAULTHANDLER, DCTFP_CRASH_BACKTRACE
 # Round-3 closing run, part B: rocprofv3 kernel stats + PMC passes of bench.py for C2, c4, c5; phase timeline; clocks.
 set -x
 cd $GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+. "$(dirname "${BASH_SOURCE[0]}")/env.sh"   # LIBC_FATAL_STDERR_, PYTHONFAULTHANDLER, DCTFP_CRASH_BACKTRACE
 # Runs tools/microbench/stage_a_pipes.hip variant by variant and samples clocks + package power beside each (GPU box).
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/stage_a_pipes tools/microbench/stage_a_pipes.hip 2>/dev/null || exit 1
 for mode in ${@:-read read_direct valu24 mfma_direct}; do
