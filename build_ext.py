@@ -86,7 +86,7 @@ def build_all(force: bool = False, verbose: bool = False):
     reccut_src = os.path.join(CSRC, 'reccut.cpp')
     if os.path.exists(reccut_src):
         if force or _stale(RECCUT_LIB_PATH, [reccut_src, os.path.join(ROOT, 'include', 'reccut.h')]):
-            cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-ffp-contract=off', '-pthread', '-shared', '-fPIC',
+            cmd = [os.environ.get('CXX', 'g++'), '-O3', '-std=c++17', '-ffp-contract=off', '-pthread', '-shared', '-fPIC',
                    '-I', os.path.join(ROOT, 'include'), '-o', RECCUT_LIB_PATH, reccut_src]
             if verbose:
                 print(' '.join(cmd))

@@ -54,7 +54,8 @@ _lib_lock = threading.Lock()
 EXPORTS = ('dctfp_version', 'dctfp_last_error', 'dctfp_create', 'dctfp_destroy', 'dctfp_quantize',
            'dctfp_idct_quant', 'dctfp_scale', 'dctfp_gather_rows', 'dctfp_contact_topk',
            'dctfp_contact_count', 'dctfp_stitch', 'dctfp_l1_matrix', 'dctfp_block_min', 'dctfp_row_select', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile', 'dctfp_host_device_pointer',
-           'dctfp_stream_synchronize', 'dctfp_runtime_info', 'dctfp_crash_handler')
+           'dctfp_stream_synchronize', 'dctfp_runtime_info', 'dctfp_crash_handler', 'dctfp_build_pieces', 'dctfp_contact_sort', 'dctfp_stitch_sizes',
+           'dctfp_stitch_sequences')
 
 
 def load(path: str = None):
@@ -144,6 +145,8 @@ def _configure(lib):
         lib.dctfp_contact_topk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.dctfp_contact_count.argtypes = [C.c_int32, C.c_double]
+        lib.dctfp_contact_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.dctfp_l1_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                         C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         lib.dctfp_block_min.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -151,6 +154,9 @@ def _configure(lib):
         lib.dctfp_row_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
                                          C.c_void_p, C.c_void_p]
         lib.dctfp_stitch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+        lib.dctfp_stitch_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+        lib.dctfp_stitch_sequences.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                               C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         lib.dctfp_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         lib.dctfp_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
         lib.dctfp_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -158,6 +164,9 @@ def _configure(lib):
         lib.dctfp_stream_synchronize.argtypes = [C.c_void_p]
         lib.dctfp_runtime_info.argtypes = [C.c_char_p, C.c_int64]
         lib.dctfp_crash_handler.argtypes = [C.c_int]
+        lib.dctfp_build_pieces.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                           C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         for fn in EXPORTS:
             if fn not in ('dctfp_last_error', 'dctfp_contact_count'):
                 getattr(lib, fn).restype = C.c_int
@@ -272,5 +281,9 @@ def load_reccut():
         lib.reccut_predict_batch.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                              C.c_int32]
+        lib.reccut_predict_packed.restype = C.c_int
+        lib.reccut_predict_packed.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int32]
         _reccut = lib
         return lib

@@ -8,6 +8,7 @@ GPU as torch tensors and the domain strings are turned into one piece table."""
 from __future__ import annotations
 
 import ctypes as C
+from itertools import chain
 from typing import List, Sequence
 
 import numpy as np
@@ -35,28 +36,111 @@ class PieceTable:
     def __init__(self, seq_rows: Sequence[int], domains: Sequence[Sequence[str]]):
         """``seq_rows[s]`` rows of sequence ``s``; ``domains[s]`` its domain strings.
         Domains whose cleaned piece list is empty are skipped, as the reference does
-        (src/fingerprint.py:190-191)."""
-        recs = []
-        self.keys: List[str] = []      # cleaned key per output row
-        self.owner: List[int] = []     # sequence index per output row
-        self.source: List[int] = []    # index of the domain string inside domains[s]
-        self.lengths: List[int] = []   # rows per output row
-        d = 0
-        for s, (n_rows, doms) in enumerate(zip(seq_rows, domains)):
-            for di, dom in enumerate(doms):
-                pieces, key = split_domain(dom, int(n_rows))
+        (src/fingerprint.py:190-191).
+
+        The strings are parsed by ``dctfp_build_pieces`` (include/dctfp.h) in one call -- a database flush has hundreds of
+        thousands of them, and the per-string Python loop this replaces cost more than the kernels of the flush
+        (profiles/r03/host_time.txt: 176 ms for 170 044 domains against 12 ms of GPU).  Strings that are not of the plain
+        form ``digits-digits[,...]`` go through ``domains.split_domain``, which keeps Python's own parsing rules."""
+        self.seq_rows = np.ascontiguousarray(np.asarray(seq_rows, dtype=np.int64))
+        n_seq = len(self.seq_rows)
+        if len(domains) != n_seq:
+            raise ValueError(f'{len(domains)} domain lists for {n_seq} sequences')
+        counts = np.fromiter(map(len, domains), dtype=np.int32, count=n_seq)
+        n_str = int(counts.sum())
+        try:
+            text = '\n'.join(chain.from_iterable(domains)).encode('ascii')
+        except (UnicodeEncodeError, TypeError):
+            text = None
+        if text is None or n_str <= 8:         # (a protein at a time: the loop over a handful of strings beats the call overhead)
+            self._init_python(list(chain.from_iterable(domains)), counts)
+            return
+        cap = len(text) // 4 + 2               # a piece is at least "b-e" and a separator
+        pieces = np.empty(cap, dtype=_lib.PIECE_DTYPE)
+        str_row = np.empty(n_str, dtype=np.int32)
+        str_len = np.empty(n_str, dtype=np.int64)
+        changed = np.empty(n_str, dtype=np.uint8)
+        key_text = C.create_string_buffer(len(text) + n_str + 1)
+        n_pieces, key_len, n_dom, n_other = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        lib = _lib.load()
+        _lib.check(lib.dctfp_build_pieces(text, len(text), counts.ctypes.data, self.seq_rows.ctypes.data, n_seq,
+                                          pieces.ctypes.data, cap, C.byref(n_pieces), str_row.ctypes.data, str_len.ctypes.data,
+                                          changed.ctypes.data, key_text, len(key_text), C.byref(key_len), C.byref(n_dom),
+                                          C.byref(n_other)), lib)
+        if n_other.value:                      # a string Python's int() / split must judge (or one with a line break inside)
+            self._init_python(list(chain.from_iterable(domains)), counts)
+            return
+        self.n_domains = n_dom.value
+        self.pieces = pieces[:n_pieces.value]
+        kept = str_row >= 0
+        self.lengths = str_len if self.n_domains == n_str else str_len[kept]
+        # keys / owner / source name the results; they are built when somebody asks (a timed loop over dctfp_quantize does not)
+        self._lazy = (domains, counts, None if self.n_domains == n_str else kept, changed,
+                      key_text.raw[:key_len.value] if key_len.value else b'')
+
+    def _resolve(self):
+        domains, counts, kept, changed, key_blob = self._lazy
+        self._lazy = None
+        n_seq, n_str = len(counts), int(counts.sum())
+        flat = list(chain.from_iterable(domains))
+        owner = np.repeat(np.arange(n_seq, dtype=np.int64), counts)
+        first = np.zeros(n_seq + 1, dtype=np.int64)
+        np.cumsum(counts, out=first[1:])
+        source = np.arange(n_str, dtype=np.int64) - np.repeat(first[:-1], counts)
+        if key_blob:
+            for i, k in zip(np.flatnonzero(changed == 1), key_blob.decode('ascii').split('\n')):
+                flat[i] = k
+        if kept is not None:
+            idx = np.flatnonzero(kept)
+            flat, owner, source = [flat[i] for i in idx], owner[idx], source[idx]
+        self._keys, self._owner, self._source = flat, owner, source
+
+    @property
+    def keys(self) -> List[str]:
+        """Cleaned key per output row: the name under which the reference files the fingerprint."""
+        if self._lazy is not None:
+            self._resolve()
+        return self._keys
+
+    @property
+    def owner(self):
+        """Sequence index per output row (numpy int64)."""
+        if self._lazy is not None:
+            self._resolve()
+        return self._owner
+
+    @property
+    def source(self):
+        """Index of the domain string inside ``domains[s]`` per output row (numpy int64)."""
+        if self._lazy is not None:
+            self._resolve()
+        return self._source
+
+    def _init_python(self, flat, counts):
+        """The same table from ``domains.split_domain`` string by string (Python's own int() / split semantics)."""
+        recs, keys, owner, source, lengths = [], [], [], [], []
+        d = i = 0
+        for s, c in enumerate(counts):
+            n_rows = int(self.seq_rows[s])
+            for di in range(int(c)):
+                pieces, key = split_domain(flat[i], n_rows)
+                i += 1
                 if not pieces:
                     continue
                 for start, n in pieces:
                     recs.append((start, n, d, s, 0))
-                self.keys.append(key)
-                self.owner.append(s)
-                self.source.append(di)
-                self.lengths.append(sum(n for _, n in pieces))
+                keys.append(key)
+                owner.append(s)
+                source.append(di)
+                lengths.append(sum(n for _, n in pieces))
                 d += 1
         self.n_domains = d
         self.pieces = np.array(recs, dtype=_lib.PIECE_DTYPE) if recs else np.zeros(0, dtype=_lib.PIECE_DTYPE)
-        self.seq_rows = np.ascontiguousarray(np.asarray(seq_rows, dtype=np.int64))
+        self._lazy = None
+        self._keys = keys
+        self._owner = np.asarray(owner, dtype=np.int64)
+        self._source = np.asarray(source, dtype=np.int64)
+        self.lengths = np.asarray(lengths, dtype=np.int64)
 
     @classmethod
     def whole_sequences(cls, seq_rows: Sequence[int]):
@@ -72,10 +156,11 @@ class PieceTable:
         self.pieces = p
         self.seq_rows = sr
         self.n_domains = n
-        self.keys = [f'1-{int(v)}' for v in sr]
-        self.owner = list(range(n))
-        self.source = [0] * n
-        self.lengths = [int(v) for v in sr]
+        self._lazy = None
+        self._keys = [f'1-{v}' for v in sr.tolist()]
+        self._owner = np.arange(n, dtype=np.int64)
+        self._source = np.zeros(n, dtype=np.int64)
+        self.lengths = sr.copy()
         return self
 
 
@@ -105,15 +190,24 @@ class LayerBatch:
             if not ts:
                 raise ValueError('empty layer')
             t0 = ts[0]
-            for t in ts:
-                if t.dim() != 2 or t.stride(1) != 1 or t.shape[1] != t0.shape[1] or t.dtype != t0.dtype \
-                        or t.device != t0.device or (t.shape[0] > 1 and t.stride(0) != t0.stride(0)):
+            if t0.dim() != 2:
+                raise ValueError('all sequences of a layer must be 2-D matrices')
+            dt, dev, width = t0.dtype, t0.device, t0.shape[1]
+            ld = t0.stride(0) if t0.shape[0] > 1 else width
+            # (one pass, a handful of attribute reads per tensor: a flush hands over thousands of them)
+            if any(t.dtype != dt or t.device != dev or t.dim() != 2 or t.shape[1] != width or t.stride(1) != 1
+                   or (t.shape[0] > 1 and t.stride(0) != ld) for t in ts):
+                # (a first sequence of one row says nothing about the row stride: take it from any longer one)
+                longer = [t for t in ts if t.dim() == 2 and t.shape[0] > 1]
+                ld = longer[0].stride(0) if longer else width
+                if any(t.dtype != dt or t.device != dev or t.dim() != 2 or t.shape[1] != width or t.stride(1) != 1
+                       or (t.shape[0] > 1 and t.stride(0) != ld) for t in ts):
                     raise ValueError('all sequences of a layer must share D, dtype, device and row stride')
-            self.ptrs = np.array([t.data_ptr() for t in ts], dtype=np.uint64)
-            self.ld = t0.stride(0) if t0.shape[0] > 1 else t0.shape[1]
-            self.n_cols = t0.shape[1]
+            self.ptrs = np.fromiter(map(torch.Tensor.data_ptr, ts), dtype=np.uint64, count=len(ts))
+            self.ld = ld
+            self.n_cols = width
             self.dtype = _dtype_code(t0)
-            self.device = t0.device
+            self.device = dev
             self._keep = ts
         if self.device.type != 'cuda':
             raise ValueError('embeddings must live on the GPU (torch device "cuda")')

@@ -1886,10 +1886,80 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
     return mark_table_used(ctx, buf, stream);
 } DCTFP_GUARD("dctfp_contact_topk")
 
-int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, int32_t n_cols, int32_t square,
-                 void* stream_v) try {
-    if (!ctx || (!jobs && n_jobs > 0)) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: NULL argument");
+// The order of the CON line (src/fingerprint.py:58-61) on the device: see include/dctfp.h.
+int dctfp_contact_sort(dctfp_ctx* ctx, const void* const* maps, const int64_t* ld, const int32_t* n_res, int32_t n_prot,
+                       double t, int32_t* out_i, int32_t* out_j, float* out_v, const int64_t* out_offs, uint8_t* sorted,
+                       void* stream_v) try {
+    if (!ctx || !maps || !ld || !n_res || !out_i || !out_j || !out_v || !out_offs || !sorted)
+        return fail(DCTFP_ERR_INVALID, "dctfp_contact_sort: NULL argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_prot < 0) return fail(DCTFP_ERR_INVALID, "dctfp_contact_sort: negative count");
+    if (n_prot == 0) return DCTFP_OK;
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // proteins grouped by the size of the sorting network that holds their k entries
+    static const int kNet[4] = {2048, 4096, 8192, 16384};
+    std::vector<int32_t> group[4];
+    for (int32_t p = 0; p < n_prot; ++p) {
+        const int64_t k = dctfp_contact_count(n_res[p], t);
+        sorted[p] = 1;
+        if (k <= 1) continue;                       // nothing to order
+        if (n_res[p] > 65536 || k > kNet[3]) {      // (i, j) do not fit 16 bits each / more entries than the LDS holds
+            sorted[p] = 0;
+            continue;
+        }
+        if (!maps[p] || ld[p] < n_res[p]) return fail(DCTFP_ERR_INVALID, "dctfp_contact_sort: protein %d: bad map", p);
+        int g = 0;
+        while (k > kNet[g]) ++g;
+        group[g].push_back(p);
+    }
+    const size_t n_jobs = group[0].size() + group[1].size() + group[2].size() + group[3].size();
+    if (n_jobs == 0) return DCTFP_OK;
+    const int buf = ctx->flip;
+    Staging& stg = ctx->staging[buf];
+    DevBuf& tab = ctx->tables[buf];
+    ctx->flip ^= 1;
+    int rc = stg.ensure(n_jobs * sizeof(TopkJob));
+    if (rc) return rc;
+    rc = tab.ensure(n_jobs * sizeof(TopkJob));
+    if (rc) return rc;
+    TopkJob* h = (TopkJob*)stg.p;
+    size_t q = 0;
+    for (int g = 0; g < 4; ++g)
+        for (int32_t p : group[g]) {
+            h[q].map = (const float*)maps[p];
+            h[q].ld = ld[p];
+            h[q].n_res = n_res[p];
+            h[q].k = (int32_t)dctfp_contact_count(n_res[p], t);
+            h[q].out_off = out_offs[p];
+            h[q].orig = p;
+            h[q].reserved = 0;
+            ++q;
+        }
+    if (ctx->tab_busy[buf]) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_free[buf], 0));
+    HIP_TRY(hipMemcpyAsync(tab.p, stg.p, n_jobs * sizeof(TopkJob), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(stg.ev, stream));
+    stg.pending = true;
+    const TopkJob* d = (const TopkJob*)tab.p;
+    size_t first = 0;
+    for (int g = 0; g < 4; ++g) {
+        const unsigned n = (unsigned)group[g].size();
+        if (n == 0) continue;
+        if (g == 0) hipLaunchKernelGGL((contact_sort_kernel<2048>), dim3(n), dim3(1024), 0, stream, d + first, out_i, out_j, out_v);
+        else if (g == 1) hipLaunchKernelGGL((contact_sort_kernel<4096>), dim3(n), dim3(1024), 0, stream, d + first, out_i, out_j, out_v);
+        else if (g == 2) hipLaunchKernelGGL((contact_sort_kernel<8192>), dim3(n), dim3(1024), 0, stream, d + first, out_i, out_j, out_v);
+        else hipLaunchKernelGGL((contact_sort_kernel<16384>), dim3(n), dim3(1024), 0, stream, d + first, out_i, out_j, out_v);
+        HIP_TRY(hipGetLastError());
+        first += n;
+    }
+    return mark_table_used(ctx, buf, stream);
+} DCTFP_GUARD("dctfp_contact_sort")
+
+}  // extern "C"
+
+namespace {
+// dctfp_stitch proper; the caller holds the context's mutex.
+int stitch_impl(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, int32_t n_cols, int32_t square, void* stream_v) {
     if (n_jobs < 0 || (!square && n_cols < 1)) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: bad count");
     if (n_jobs == 0) return DCTFP_OK;
     if (n_jobs > 65535 * 64) return fail(DCTFP_ERR_LIMIT, "dctfp_stitch: too many windows in one call");
@@ -1950,7 +2020,83 @@ int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, i
         }
     }
     return mark_table_used(ctx, buf, stream);
+}
+
+// Window geometry of one sequence (src/embedding.py:123-150, :185-188): see dctfp_stitch_sizes / dctfp_stitch_sequences.
+// Returns the rows (embeddings) or the side (contact maps) of the stitched result, or -1 where the reference's torch
+// expression would fail to broadcast.  `emit(window, dst_row_offset, n_avg)` is called per window when given.
+template <typename Emit>
+int64_t stitch_geometry(const int32_t* rows, int64_t n_win, int32_t step, bool square, Emit emit) {
+    if (n_win < 1 || rows[0] < 1) return -1;
+    int64_t size = rows[0];
+    emit((int64_t)0, (int64_t)0, (int32_t)0);
+    for (int64_t w = 1; w < n_win; ++w) {
+        if (rows[w] < 1) return -1;
+        if (!square) {      // run[-olp:] = (run[-olp:] + new[:olp]) / 2; cat(new[olp:])
+            if (rows[w] <= step || size < step) return -1;
+            emit(w, size - step, step);
+            size += rows[w] - step;
+        } else {            // combine_contacts: the window lands at offset inc * w, its overlap with the running map is averaged
+            const int64_t off = (int64_t)step * w;
+            if (off > size) return -1;
+            emit(w, off, (int32_t)std::min<int64_t>(size - off, rows[w]));
+            size = off + rows[w];
+        }
+    }
+    return size;
+}
+}  // namespace
+
+extern "C" {
+
+int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, int32_t n_cols, int32_t square,
+                 void* stream_v) try {
+    if (!ctx || (!jobs && n_jobs > 0)) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return stitch_impl(ctx, jobs, n_jobs, n_cols, square, stream_v);
 } DCTFP_GUARD("dctfp_stitch")
+
+int dctfp_stitch_sizes(const int32_t* win_rows, const int64_t* seq_win, int64_t n_seq, int32_t step, int32_t square,
+                       int64_t* out_rows) try {
+    if (!win_rows || !seq_win || !out_rows || n_seq < 0 || step < 0) return fail(DCTFP_ERR_INVALID, "dctfp_stitch_sizes: bad argument");
+    for (int64_t s = 0; s < n_seq; ++s) {
+        const int64_t n = seq_win[s + 1] - seq_win[s];
+        out_rows[s] = stitch_geometry(win_rows + seq_win[s], n, step, square != 0, [](int64_t, int64_t, int32_t) {});
+        if (out_rows[s] < 0)
+            return fail(DCTFP_ERR_SHAPE, square ? "sequence %lld: window offset beyond the running contact map"
+                                                : "sequence %lld: a window is not longer than the overlap", (long long)s);
+    }
+    return DCTFP_OK;
+} DCTFP_GUARD("dctfp_stitch_sizes")
+
+int dctfp_stitch_sequences(dctfp_ctx* ctx, const void* const* win, const int32_t* win_rows, const int64_t* win_ld,
+                           const int64_t* seq_win, int64_t n_seq, void* const* dst, const int64_t* dst_ld, int32_t n_cols,
+                           int32_t step, int32_t square, void* stream_v) try {
+    if (!ctx || !win || !win_rows || !win_ld || !seq_win || !dst || !dst_ld) return fail(DCTFP_ERR_INVALID, "dctfp_stitch_sequences: NULL argument");
+    if (n_seq < 0 || step < 0) return fail(DCTFP_ERR_INVALID, "dctfp_stitch_sequences: bad count");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::vector<dctfp_stitch_job> jobs;
+    jobs.reserve((size_t)(n_seq > 0 ? seq_win[n_seq] - seq_win[0] : 0));
+    for (int64_t s = 0; s < n_seq; ++s) {
+        const int64_t w0 = seq_win[s], n = seq_win[s + 1] - w0;
+        const int64_t size = stitch_geometry(win_rows + w0, n, step, square != 0, [&](int64_t w, int64_t off, int32_t n_avg) {
+            dctfp_stitch_job j;
+            j.src = win[w0 + w];
+            j.dst = (char*)dst[s] + (size_t)(square ? off * dst_ld[s] + off : off * dst_ld[s]) * sizeof(float);
+            j.ld_src = win_ld[w0 + w];
+            j.ld_dst = dst_ld[s];
+            j.n_rows = win_rows[w0 + w];
+            j.n_avg = n_avg;
+            j.level = (int32_t)w;
+            j.reserved = 0;
+            jobs.push_back(j);
+        });
+        if (size < 0)
+            return fail(DCTFP_ERR_SHAPE, square ? "sequence %lld: window offset beyond the running contact map"
+                                                : "sequence %lld: a window is not longer than the overlap", (long long)s);
+    }
+    return stitch_impl(ctx, jobs.data(), (int64_t)jobs.size(), n_cols, square, stream_v);
+} DCTFP_GUARD("dctfp_stitch_sequences")
 
 int dctfp_l1_matrix(dctfp_ctx* ctx, const int8_t* a, int64_t na, int64_t lda, const int8_t* b, int64_t nb, int64_t ldb,
                     int32_t d, int32_t* out, int64_t ldo, void* stream_v) try {
@@ -2022,6 +2168,121 @@ int64_t dctfp_contact_count(int32_t n_res, double t) {
     return tot > cand ? cand : tot;
 }
 
+
+// ---- host-side table builders (no GPU work): what the Python front end used to do per domain / per window in loops ----
+
+/* Fingerprint.get_doms' domain-string rules (src/fingerprint.py:163-169) for a whole batch -> dctfp_piece[].
+ * See include/dctfp.h.  Only strings of the plain form  digits-digits[,digits-digits]*  are handled here (what RecCut
+ * prints and every reference test uses); anything else -- signs, blanks, underscores, empty fields: whatever Python's
+ * int() and str.split would accept or reject -- is counted in *n_other and left to the caller's own parser. */
+int dctfp_build_pieces(const char* text, int64_t text_len, const int32_t* str_count, const int64_t* seq_rows, int32_t n_seq,
+                       dctfp_piece* pieces, int64_t piece_cap, int64_t* n_pieces, int32_t* str_row, int64_t* str_len,
+                       uint8_t* str_changed, char* key_text, int64_t key_cap, int64_t* key_len, int64_t* n_domains,
+                       int64_t* n_other) try {
+    if (!text || !str_count || !seq_rows || !pieces || !n_pieces || !str_row || !str_len || !str_changed || !key_len || !n_domains || !n_other)
+        return fail(DCTFP_ERR_INVALID, "dctfp_build_pieces: NULL argument");
+    if (n_seq < 0 || text_len < 0 || piece_cap < 0 || key_cap < 0) return fail(DCTFP_ERR_INVALID, "dctfp_build_pieces: negative size");
+    struct Part { const char* p; int32_t len; int64_t beg, end; };
+    std::vector<Part> parts;
+    int64_t np = 0, nd = 0, kl = 0, other = 0, istr = 0;
+    const char* cur = text;
+    const char* const fin = text + text_len;
+    for (int32_t s = 0; s < n_seq; ++s) {
+        const int64_t L = seq_rows[s];
+        for (int32_t k = 0; k < str_count[s]; ++k, ++istr) {
+            if (cur > fin) return fail(DCTFP_ERR_INVALID, "dctfp_build_pieces: fewer strings in the text than str_count says");
+            const char* e = cur;
+            while (e < fin && *e != '\n') ++e;
+            // ---- split at ',' and parse "digits-digits"
+            parts.clear();
+            bool plain = e > cur;
+            for (const char* q = cur; plain && q <= e;) {
+                const char* f = q;
+                while (f < e && *f != ',') ++f;
+                Part pt{q, (int32_t)(f - q), 0, 0};
+                const char* c = q;
+                int digits = 0;
+                while (c < f && *c >= '0' && *c <= '9' && digits < 18) { pt.beg = pt.beg * 10 + (*c - '0'); ++c; ++digits; }
+                if (digits == 0 || c >= f || *c != '-') { plain = false; break; }
+                ++c;
+                digits = 0;
+                while (c < f && *c >= '0' && *c <= '9' && digits < 18) { pt.end = pt.end * 10 + (*c - '0'); ++c; ++digits; }
+                if (digits == 0 || c != f) { plain = false; break; }
+                parts.push_back(pt);
+                q = f + 1;
+                if (f == e) break;
+            }
+            str_row[istr] = -1;
+            str_len[istr] = 0;
+            str_changed[istr] = 0;
+            if (!plain) {
+                str_changed[istr] = 2;
+                ++other;
+                cur = e + 1;
+                continue;
+            }
+            // ---- the reference's loop: `for r in regions: if (beg or end) > L: regions.remove(r)` -- the list shrinks
+            // under its own iterator, so the part after a removed one is never looked at but stays in the key; remove()
+            // takes out the FIRST equal string
+            const int64_t first_piece = np;
+            int64_t rows = 0;
+            bool changed = false;
+            for (size_t i = 0; i < parts.size();) {
+                const Part pt = parts[i];
+                if ((pt.beg ? pt.beg : pt.end) > L) {
+                    size_t victim = i;
+                    for (size_t v = 0; v < i; ++v)
+                        if (parts[v].len == pt.len && memcmp(parts[v].p, pt.p, (size_t)pt.len) == 0) { victim = v; break; }
+                    parts.erase(parts.begin() + (ptrdiff_t)victim);
+                    changed = true;
+                    ++i;  // (the iterator advances regardless)
+                    continue;
+                }
+                // embed[beg - 1 : end] with Python's slice rules
+                int64_t start = pt.beg - 1, stop = pt.end;
+                if (start < 0) { start += L; if (start < 0) start = 0; }
+                if (start > L) start = L;
+                if (stop > L) stop = L;
+                if (stop > start) {
+                    if (np >= piece_cap) return fail(DCTFP_ERR_INVALID, "dctfp_build_pieces: piece_cap %lld too small", (long long)piece_cap);
+                    if (stop - start > 0x7fffffff) return fail(DCTFP_ERR_LIMIT, "dctfp_build_pieces: piece longer than 2^31 rows");
+                    pieces[np].row_start = start;
+                    pieces[np].n_rows = (int32_t)(stop - start);
+                    pieces[np].domain = (int32_t)nd;
+                    pieces[np].seq = s;
+                    pieces[np].reserved = 0;
+                    ++np;
+                    rows += stop - start;
+                }
+                ++i;
+            }
+            if (changed) {  // the cleaned key: the surviving parts joined by ','
+                str_changed[istr] = 1;
+                for (size_t i = 0; i < parts.size(); ++i) {
+                    if (kl + parts[i].len + 1 > key_cap) return fail(DCTFP_ERR_INVALID, "dctfp_build_pieces: key_cap too small");
+                    if (i) key_text[kl++] = ',';
+                    memcpy(key_text + kl, parts[i].p, (size_t)parts[i].len);
+                    kl += parts[i].len;
+                }
+                if (kl + 1 > key_cap) return fail(DCTFP_ERR_INVALID, "dctfp_build_pieces: key_cap too small");
+                key_text[kl++] = '\n';
+            }
+            if (np > first_piece) {
+                if (nd >= 0x7fffffff) return fail(DCTFP_ERR_LIMIT, "dctfp_build_pieces: more than 2^31 domains");
+                str_row[istr] = (int32_t)nd;
+                str_len[istr] = rows;
+                ++nd;
+            }
+            cur = e + 1;
+        }
+    }
+    if (istr > 0 && cur != fin + 1) ++other;  // more line breaks in the text than strings: one of them had a '\n' inside
+    *n_pieces = np;
+    *n_domains = nd;
+    *key_len = kl;
+    *n_other = other;
+    return DCTFP_OK;
+} DCTFP_GUARD("dctfp_build_pieces")
 
 // ---- diagnostics: which HIP / HSA runtime this library is bound to, and a crash handler that names the failing frame ----
 

@@ -1782,6 +1782,53 @@ __global__ __launch_bounds__(1024) void contact_topk_kernel(const TopkJob* __res
 
 
 // ---------------------------------------------------------------------------
+// Order of the selected contacts (the CON line of the .ce file, src/fingerprint.py:58-61, :69-73): value descending,
+// ties in (i, j) ascending order -- Python's stable sort with reverse=True over pairs appended i-major.  One workgroup
+// per protein sorts its k entries in LDS (bitonic network over 64-bit keys: the inverted order-preserving image of the
+// value above (i << 16 | j)) and writes them back in place; the value is re-read from the map, so its bits are the
+// original ones (-0.0 prints as "-0.000000" in the reference too).  N = capacity of the network (a power of two >= k).
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(1024) void contact_sort_kernel(const TopkJob* __restrict__ jobs, int32_t* __restrict__ out_i,
+                                                             int32_t* __restrict__ out_j, float* __restrict__ out_v) {
+    __shared__ unsigned long long keys[N];
+    const TopkJob job = jobs[blockIdx.x];
+    const int k = job.k;
+    if (k <= 1 || k > N) return;  // (the host sends a protein to a network that holds it)
+    int32_t* __restrict__ oi = out_i + job.out_off;
+    int32_t* __restrict__ oj = out_j + job.out_off;
+    float* __restrict__ ov = out_v + job.out_off;
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+        unsigned long long key = ~0ull;
+        if (p < k) key = ((unsigned long long)(~topk_key(ov[p])) << 32) | ((uint32_t)oi[p] << 16) | (uint32_t)oj[p];
+        keys[p] = key;
+    }
+    __syncthreads();
+    for (int size = 2; size <= N; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int q = threadIdx.x; q < N / 2; q += blockDim.x) {
+                const int lo = ((q & ~(stride - 1)) << 1) | (q & (stride - 1));
+                const int hi = lo | stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == up) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int p = threadIdx.x; p < k; p += blockDim.x) {
+        const uint32_t ij = (uint32_t)keys[p];
+        const int i = (int)(ij >> 16), j = (int)(ij & 0xffffu);
+        oi[p] = i;
+        oj[p] = j;
+        ov[p] = job.map[(size_t)i * job.ld + j];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Contact top-k of LONG proteins (L >= ~1500): the same selection, spread over many workgroups.  One workgroup per
 // (protein, stripe of rows) -- stripes hold about the same number of candidate pairs -- and one launch per step instead of
 // one workgroup walking the whole L x L map five times (13 ms for a 5 000-residue protein):

@@ -117,71 +117,92 @@ def stitch_embeddings(windows: List[torch.Tensor], overlap: int = OVERLAP) -> to
     return stitch_embeddings_batch([windows], overlap)[0]
 
 
-def stitch_embeddings_batch(seq_windows: List[List[torch.Tensor]], overlap: int = OVERLAP) -> List[torch.Tensor]:
-    """Same for many sequences: one kernel launch per window index for the whole batch."""
-    outs, jobs, keep = [], [], []
-    device = None
-    n_cols = None
-    for windows in seq_windows:
-        ws = []
-        for w in windows:
+def _float_windows(seq_windows):
+    """Flat list of the windows as float32 tensors with contiguous rows + windows per sequence.  The common case (windows
+    straight off the model) costs two attribute reads per window."""
+    flat = [w for windows in seq_windows for w in windows]
+    if any(w.dtype != torch.float32 or w.stride(-1) != 1 or w.dim() != 2 for w in flat):
+        fixed = []
+        for w in flat:
+            if w.dim() != 2:
+                raise ValueError(f'a window must be a 2-D tensor, got shape {tuple(w.shape)}')
             if w.dtype != torch.float32:
                 w = w.float()
             if w.stride(-1) != 1:
                 w = w.contiguous()
-            ws.append(w)
-        if device is None:
-            device, n_cols = ws[0].device, ws[0].shape[1]
-        if device.type != 'cuda':
-            raise ValueError('windows must be GPU tensors (no CPU fallback)')
-        total = ws[0].shape[0]
-        starts = [0]
-        for w in ws[1:]:
-            if w.shape[0] <= overlap or total < overlap:
-                raise ValueError('a window is not longer than the overlap')     # torch would fail to broadcast
-            starts.append(total - overlap)
-            total += w.shape[0] - overlap
-        out = torch.empty((total, n_cols), dtype=torch.float32, device=device)
-        for lvl, (w, st) in enumerate(zip(ws, starts)):
-            jobs.append(StitchJob(w.data_ptr(), out.data_ptr() + st * out.stride(0) * 4,
-                                  w.stride(0) if w.shape[0] > 1 else n_cols, out.stride(0), w.shape[0],
-                                  overlap if lvl else 0, lvl, 0))
-        keep.append(ws)
-        outs.append(out)
-    if jobs:
-        _stitch(jobs, n_cols, False, device)
+            fixed.append(w)
+        flat = fixed
+    return flat, np.fromiter(map(len, seq_windows), dtype=np.int64, count=len(seq_windows))
+
+
+def _stitch_sequences(flat, counts, step: int, square: bool, n_cols: int):
+    """Geometry (``dctfp_stitch_sizes``), ONE allocation for all results, launches (``dctfp_stitch_sequences``).  Returns
+    the per-sequence results as views of that allocation."""
+    device = flat[0].device
+    if device.type != 'cuda':
+        raise ValueError('windows must be GPU tensors (no CPU fallback)')
+    n_seq, n_win = len(counts), len(flat)
+    seq_win = np.zeros(n_seq + 1, dtype=np.int64)
+    np.cumsum(counts, out=seq_win[1:])
+    rows = np.fromiter((w.shape[0] for w in flat), dtype=np.int32, count=n_win)
+    lds = np.fromiter((w.stride(0) for w in flat), dtype=np.int64, count=n_win)
+    ptrs = np.fromiter(map(torch.Tensor.data_ptr, flat), dtype=np.uint64, count=n_win)
+    if square:
+        lds = np.where(rows > 1, lds, rows)
+    else:
+        lds = np.where(rows > 1, lds, n_cols)
+    lib = _lib.load()
+    sizes = np.empty(n_seq, dtype=np.int64)
+    rc = lib.dctfp_stitch_sizes(rows.ctypes.data, seq_win.ctypes.data, n_seq, int(step), 1 if square else 0, sizes.ctypes.data)
+    if rc == _lib.DCTFP_ERR_SHAPE:
+        raise ValueError(lib.dctfp_last_error().decode())          # torch would fail to broadcast in the reference
+    _lib.check(rc, lib)
+    if square:
+        elems = sizes * sizes
+        big = torch.zeros(int(elems.sum()), dtype=torch.float32, device=device)      # new_mat = torch.zeros, :143
+        outs = [v.view(n, n) for v, n in zip(torch.split(big, elems.tolist()), sizes.tolist())]
+        dst_ld = sizes
+    else:
+        elems = sizes * n_cols
+        big = torch.empty((int(sizes.sum()), n_cols), dtype=torch.float32, device=device)
+        outs = list(torch.split(big, sizes.tolist()))
+        dst_ld = np.full(n_seq, n_cols, dtype=np.int64)
+    first = np.zeros(n_seq, dtype=np.uint64)
+    np.cumsum(elems[:-1], out=first[1:].view(np.int64))
+    dst = np.uint64(big.data_ptr()) + first * np.uint64(4)
+    ctx = _lib.get_context(device.index)
+    stream = torch.cuda.current_stream(device)
+    _lib.check(lib.dctfp_stitch_sequences(ctx.handle, ptrs.ctypes.data, rows.ctypes.data, lds.ctypes.data, seq_win.ctypes.data,
+                                          n_seq, dst.ctypes.data, np.ascontiguousarray(dst_ld, dtype=np.int64).ctypes.data,
+                                          int(n_cols), int(step), 1 if square else 0, C.c_void_p(stream.cuda_stream)), lib)
     return outs
+
+
+def stitch_embeddings_batch(seq_windows: List[List[torch.Tensor]], overlap: int = OVERLAP) -> List[torch.Tensor]:
+    """Same for many sequences: one kernel launch per window index for the whole batch.  The window geometry is worked
+    out in C (``dctfp_stitch_sequences``); the results are views of ONE allocation (keep one and all stay alive)."""
+    if not seq_windows:
+        return []
+    flat, counts = _float_windows(seq_windows)
+    if (counts < 1).any():
+        raise ValueError('a sequence without windows')
+    n_cols = flat[0].shape[1]
+    if any(w.shape[1] != n_cols for w in flat):
+        raise ValueError('windows of different widths')
+    return _stitch_sequences(flat, counts, overlap, False, n_cols)
 
 
 def stitch_contacts_batch(seq_windows: List[List[torch.Tensor]], inc: int) -> List[torch.Tensor]:
     """``combine_contacts`` applied window after window (src/embedding.py:123-150, :188): window i's
     map lands at offset ``inc * i``; the part overlapping the running map is averaged."""
-    outs, jobs, keep = [], [], []
-    device = None
-    for windows in seq_windows:
-        ws = [w.float().contiguous() if (w.dtype != torch.float32 or w.stride(-1) != 1) else w for w in windows]
-        if device is None:
-            device = ws[0].device
-        if device.type != 'cuda':
-            raise ValueError('windows must be GPU tensors (no CPU fallback)')
-        size = ws[0].shape[0]
-        geo = [(0, 0)]
-        for i, w in enumerate(ws[1:], start=1):
-            olp = inc * i
-            if olp > size:
-                raise ValueError('window offset beyond the running contact map')
-            geo.append((olp, size - olp))
-            size = olp + w.shape[0]
-        out = torch.zeros((size, size), dtype=torch.float32, device=device)
-        for lvl, (w, (off, navg)) in enumerate(zip(ws, geo)):
-            jobs.append(StitchJob(w.data_ptr(), out.data_ptr() + (off * out.stride(0) + off) * 4,
-                                  w.stride(0) if w.shape[0] > 1 else w.shape[1], out.stride(0), w.shape[0],
-                                  min(navg, w.shape[0]), lvl, 0))
-        keep.append(ws)
-        outs.append(out)
-    if jobs:
-        _stitch(jobs, 1, True, device)
-    return outs
+    if not seq_windows:
+        return []
+    flat, counts = _float_windows(seq_windows)
+    if (counts < 1).any():
+        raise ValueError('a sequence without windows')
+    if any(w.shape[0] != w.shape[1] for w in flat):
+        raise ValueError('a contact window must be square')
+    return _stitch_sequences(flat, counts, inc, True, 1)
 
 
 @dataclass

@@ -55,6 +55,9 @@ def _to_device_matrix(x, device=None, keep_half: bool = False) -> torch.Tensor:
     Every dtype the reference accepts is promoted exactly (it computes in float64)."""
     if isinstance(x, torch.Tensor):
         t = x
+        if t.is_cuda and t.dim() == 2 and t.stride(1) == 1 and (t.dtype == torch.float32 or t.dtype == torch.float64) \
+                and (t.shape[0] <= 1 or t.stride(0) >= t.shape[1]):
+            return t                             # straight off the language model: nothing to do
     else:
         a = np.asarray(x)
         if a.dtype not in (np.float32, np.float64):

@@ -12,6 +12,7 @@ subprocess:
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import List, Sequence
 
 import numpy as np
@@ -26,6 +27,9 @@ CUT2_DEFAULT = 0.07      # src/RecCut.cpp:13
 def _contact_tensor(contacts, n_res: int, device=None) -> torch.Tensor:
     if isinstance(contacts, torch.Tensor):
         t = contacts
+        if t.dtype == torch.float32 and t.is_cuda and t.dim() == 2 and t.shape[0] == n_res and t.shape[1] == n_res \
+                and t.stride(1) == 1:
+            return t                            # straight off the language model: nothing to do
     else:
         t = torch.from_numpy(np.ascontiguousarray(np.asarray(contacts, dtype=np.float32)))
     t = t.reshape(n_res, n_res)                 # cta = self.contacts.reshape(slen, slen)
@@ -40,17 +44,36 @@ def _contact_tensor(contacts, n_res: int, device=None) -> torch.Tensor:
     return t
 
 
+_PINNED = threading.local()
+
+
+def _pinned(name: str, dtype, n: int) -> torch.Tensor:
+    """A page-locked staging buffer of this thread (grown geometrically): device -> host copies of a flush's contacts run
+    at the PCIe rate instead of the pageable one."""
+    buf = getattr(_PINNED, name, None)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n + n // 2, 1 << 16), dtype=dtype, pin_memory=True)
+        setattr(_PINNED, name, buf)
+    return buf[:n]
+
+
 def top_contacts_batch(maps: Sequence[torch.Tensor], t: float, sort: bool = True):
     """Top ``int(t*L)`` contacts of each map.  Returns (offs, i, j, v) as numpy arrays: protein
     p's contacts are ``[offs[p], offs[p+1])``; with ``sort`` they are ordered by (-v, i, j) -- the
-    order of the reference's CON line (the domain cutter itself does not care about the order)."""
+    order of the reference's CON line (the domain cutter itself does not care about the order).
+
+    Selection (``dctfp_contact_topk``) and order (``dctfp_contact_sort``) both happen on the GPU; what comes back is one
+    copy of the selected entries through page-locked buffers."""
     n = len(maps)
     if n == 0:
         return np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
     device = maps[0].device
     lib = _lib.load()
-    n_res = np.array([m.shape[0] for m in maps], dtype=np.int32)
-    counts = np.array([lib.dctfp_contact_count(int(L), float(t)) for L in n_res], dtype=np.int64)
+    n_res = np.fromiter((m.shape[0] for m in maps), dtype=np.int32, count=n)
+    # dctfp_contact_count for all proteins at once: min(int(t * L), pairs with j >= i + 5)
+    L64 = n_res.astype(np.int64)
+    cand = np.where(L64 >= 6, (L64 - 5) * (L64 - 4) // 2, 0)
+    counts = np.minimum(np.maximum((float(t) * L64.astype(np.float64)).astype(np.int64), 0), cand)
     offs = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(counts, out=offs[1:])
     total = int(offs[-1])
@@ -58,16 +81,29 @@ def top_contacts_batch(maps: Sequence[torch.Tensor], t: float, sort: bool = True
     oj = torch.empty(max(total, 1), dtype=torch.int32, device=device)
     ov = torch.empty(max(total, 1), dtype=torch.float32, device=device)
     on = torch.zeros(n, dtype=torch.int32, device=device)
-    ptrs = np.array([m.data_ptr() for m in maps], dtype=np.uint64)
-    lds = np.array([m.stride(0) if m.shape[0] > 1 else max(1, m.shape[1]) for m in maps], dtype=np.int64)
+    ptrs = np.fromiter((m.data_ptr() for m in maps), dtype=np.uint64, count=n)
+    lds = np.fromiter((m.stride(0) if m.shape[0] > 1 else max(1, m.shape[1]) for m in maps), dtype=np.int64, count=n)
     ctx = _lib.get_context(device.index)
     stream = torch.cuda.current_stream(device)
+    sp = C.c_void_p(stream.cuda_stream)
     _lib.check(lib.dctfp_contact_topk(ctx.handle, ptrs.ctypes.data, lds.ctypes.data, n_res.ctypes.data, n, float(t),
-                                      oi.data_ptr(), oj.data_ptr(), ov.data_ptr(), offs.ctypes.data, on.data_ptr(),
-                                      C.c_void_p(stream.cuda_stream)))
-    hi, hj, hv = oi[:total].cpu().numpy(), oj[:total].cpu().numpy(), ov[:total].cpu().numpy()
-    assert (on.cpu().numpy() == counts).all()
-    for p in range(n if sort else 0):
+                                      oi.data_ptr(), oj.data_ptr(), ov.data_ptr(), offs.ctypes.data, on.data_ptr(), sp))
+    on_device = np.ones(n, dtype=np.uint8)
+    if sort:
+        _lib.check(lib.dctfp_contact_sort(ctx.handle, ptrs.ctypes.data, lds.ctypes.data, n_res.ctypes.data, n, float(t),
+                                          oi.data_ptr(), oj.data_ptr(), ov.data_ptr(), offs.ctypes.data,
+                                          on_device.ctypes.data, sp))
+    pi, pj, pv, pn = (_pinned('i', torch.int32, total), _pinned('j', torch.int32, total), _pinned('v', torch.float32, total),
+                      _pinned('n', torch.int32, n))
+    pi.copy_(oi[:total], non_blocking=True)
+    pj.copy_(oj[:total], non_blocking=True)
+    pv.copy_(ov[:total], non_blocking=True)
+    pn.copy_(on, non_blocking=True)
+    stream.synchronize()
+    hi, hj, hv = pi.numpy().copy(), pj.numpy().copy(), pv.numpy().copy()
+    if not (pn.numpy() == counts).all():
+        raise RuntimeError('dctfp_contact_topk wrote a different number of contacts than dctfp_contact_count says')
+    for p in (np.flatnonzero(on_device == 0) if sort else ()):       # longer than the device network holds (L > 6 301)
         a, b = offs[p], offs[p + 1]
         order = np.lexsort((hj[a:b], hi[a:b], -hv[a:b].astype(np.float64)))
         hi[a:b], hj[a:b], hv[a:b] = hi[a:b][order], hj[a:b][order], hv[a:b][order]
@@ -103,24 +139,26 @@ def domains_from_contacts(n_res: Sequence[int], offs, ci, cj, cv, cut1=CUT1_DEFA
     ci = np.ascontiguousarray(ci, dtype=np.int32)
     cj = np.ascontiguousarray(cj, dtype=np.int32)
     cv = np.ascontiguousarray(cv, dtype=np.float32)
-    stride = int(max(64, 16 * int(n_res.max()) if n else 64))
-    buf = np.zeros((n, stride), dtype=np.uint8)
+    if n == 0:
+        return []
+    cap = 64 * n + 16 * int(n_res.astype(np.int64).sum())      # a domain piece "b-e," is at most 12 bytes per residue it holds
+    buf = np.empty(cap, dtype=np.uint8)
+    out_off = np.zeros(n + 1, dtype=np.int64)
     nd = np.zeros(n, dtype=np.int32)
     rc = np.zeros(n, dtype=np.int32)
-    ret = lib.reccut_predict_batch(n, n_res.ctypes.data, offs.ctypes.data, ci.ctypes.data, cj.ctypes.data,
-                                   cv.ctypes.data, float(cut1), float(cut2), buf.ctypes.data, stride, nd.ctypes.data,
-                                   rc.ctypes.data, int(threads))
+    ret = lib.reccut_predict_packed(n, n_res.ctypes.data, offs.ctypes.data, ci.ctypes.data, cj.ctypes.data,
+                                    cv.ctypes.data, float(cut1), float(cut2), buf.ctypes.data, cap, out_off.ctypes.data,
+                                    nd.ctypes.data, rc.ctypes.data, int(threads))
     if ret != 0:
-        raise RuntimeError(f'reccut_predict_batch failed: {ret}')
-    out = []
-    for p in range(n):
-        if rc[p] != 0:
-            # the reference would raise CalledProcessError (RecCut exit != 0) or crash
-            raise RuntimeError(f'reccut: protein {p}: error {int(rc[p])} '
-                               f'({"undefined behaviour in the reference at this input" if rc[p] == -3 else "invalid input"})')
-        text = bytes(buf[p]).split(b'\0', 1)[0].decode()
-        out.append(text.split(';')[:-1])
-    return out
+        raise RuntimeError(f'reccut_predict_packed failed: {ret}')
+    if rc.any():
+        p = int(np.flatnonzero(rc)[0])
+        # the reference would raise CalledProcessError (RecCut exit != 0) or crash
+        raise RuntimeError(f'reccut: protein {p}: error {int(rc[p])} '
+                           f'({"undefined behaviour in the reference at this input" if rc[p] == -3 else "invalid input"})')
+    text = buf[:int(out_off[-1])].tobytes().decode('ascii')
+    bounds = out_off.tolist()
+    return [text[a:b].split(';')[:-1] for a, b in zip(bounds[:-1], bounds[1:])]
 
 
 def predict_domains(fp, threshold: float) -> List[str]:

@@ -81,6 +81,26 @@ typedef struct {
 int dctfp_version(void);
 const char* dctfp_last_error(void);
 
+/* The domain-string half of Fingerprint.get_doms (src/fingerprint.py:163-169) for a whole batch, on the host: every
+ * domain string ("b-e" or "b-e,b-e,...", 1-based inclusive) becomes its dctfp_piece records, with the reference's
+ * behaviour kept exactly: `(int(beg) or int(end)) > L` drops a piece, the list shrinks under its own iterator (the piece
+ * after a dropped one is never looked at but stays in the key), remove() takes out the first equal string, `end > L` is
+ * clipped, `beg == 0` is the slice [-1:end]; a domain whose cleaned piece list is empty is skipped (:190-191).
+ *   text, text_len : all strings in sequence order, separated by '\n';  str_count[s] = strings of sequence s
+ *   seq_rows[s]    : rows of sequence s
+ *   pieces         : out, room for piece_cap records (number of strings + number of ',' in text is always enough)
+ *   str_row[i]     : out, the output row (domain index) of string i, or -1 when it is skipped
+ *   str_len[i]     : out, rows of that domain
+ *   str_changed[i] : out, 0 = the key under which the reference files the fingerprint is the string itself; 1 = a piece was
+ *                    removed, the cleaned key is the next '\n'-terminated entry of key_text; 2 = the string is not of the
+ *                    plain form digits-digits[,digits-digits]* -- counted in *n_other and left to the caller's own parser
+ *                    (whatever Python's int() / str.split would make of it)
+ * Host memory only; needs no GPU and no context. */
+int dctfp_build_pieces(const char* text, int64_t text_len, const int32_t* str_count, const int64_t* seq_rows, int32_t n_seq,
+                       dctfp_piece* pieces, int64_t piece_cap, int64_t* n_pieces, int32_t* str_row, int64_t* str_len,
+                       uint8_t* str_changed, char* key_text, int64_t key_cap, int64_t* key_len, int64_t* n_domains,
+                       int64_t* n_other);
+
 /* Context on HIP device `device`: owns the cosine bases, job tables and the float64
  * scratch between the two kernels.  Replaces nothing in the reference (it has no state). */
 int dctfp_create(int device, dctfp_ctx** out);
@@ -132,6 +152,15 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
                        const int64_t* out_offs, int32_t* out_n, void* stream);
 int64_t dctfp_contact_count(int32_t n_res, double t);
 
+/* The ORDER of the selected contacts as the reference's CON line has them (src/fingerprint.py:58-61: sorted by value,
+ * reverse=True, Python's stable sort over pairs appended i-major): value descending, ties in (i, j) ascending order.
+ * Sorts, in place and on the device, what dctfp_contact_topk wrote for the same arguments (one workgroup per protein, a
+ * bitonic network in LDS).  sorted[p] (host, out) = 1 when protein p is in that order afterwards, 0 when it is left as it
+ * was (more than 16 384 selected contacts -- L > 6 301 at t = 2.6 -- or L > 65 536: the caller orders those itself). */
+int dctfp_contact_sort(dctfp_ctx* ctx, const void* const* maps, const int64_t* ld, const int32_t* n_res, int32_t n_prot,
+                       double t, int32_t* out_i, int32_t* out_j, float* out_v, const int64_t* out_offs, uint8_t* sorted,
+                       void* stream);
+
 /* The chunk stitcher of Embedding.embed_seq (src/embedding.py:153-192): a sequence longer than
  * maxlen is embedded in windows; per layer `run[-200:] = (run[-200:] + new[:200]) / 2` then
  * `cat(new[200:])` (:185-187), and for the contact maps combine_contacts (:123-150).  One job =
@@ -155,6 +184,23 @@ typedef struct {
 } dctfp_stitch_job;
 int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, int32_t n_cols, int32_t square,
                  void* stream);
+
+/* The same for whole sequences, the window geometry worked out here instead of by the caller (the per-window Python of a
+ * batch cost four times its kernels): sequence s owns the windows [seq_win[s], seq_win[s+1]) in order; win_rows / win /
+ * win_ld give each window's rows, device pointer and leading dimension.
+ *   square = 0, step = the overlap (200 in the reference, src/embedding.py:163): window w > 0 starts `step` rows before
+ *                the end of the running embedding, those rows are averaged, the rest appended (:185-187);
+ *   square = 1, step = maxlen - overlap: window w's map lands at offset step * w of the running map, the part they share
+ *                is averaged (combine_contacts, :123-150).
+ * dctfp_stitch_sizes (host only, no context): rows / side of each stitched result, so that the caller can allocate;
+ * DCTFP_ERR_SHAPE where the reference's torch expression would fail to broadcast (a window not longer than the overlap,
+ * a window offset beyond the running map).  dctfp_stitch_sequences: dst[s] = device pointer of sequence s's result
+ * (dst_ld[s] floats per row; contact maps zero-filled by the caller), then the launches of dctfp_stitch. */
+int dctfp_stitch_sizes(const int32_t* win_rows, const int64_t* seq_win, int64_t n_seq, int32_t step, int32_t square,
+                       int64_t* out_rows);
+int dctfp_stitch_sequences(dctfp_ctx* ctx, const void* const* win, const int32_t* win_rows, const int64_t* win_ld,
+                           const int64_t* seq_win, int64_t n_seq, void* const* dst, const int64_t* dst_ld, int32_t n_cols,
+                           int32_t step, int32_t square, void* stream);
 
 /* L1 distance matrix between two sets of int8 fingerprints, the quantity under the
  * reference's similarity scores 1 - min(L1 / 17000, 1) (src/dct-sim.py:12-26) and

@@ -49,6 +49,13 @@ int reccut_predict_batch(int64_t n_prot, const int32_t* n_res, const int64_t* of
                          const int32_t* cj, const float* prob, double cut1, double cut2, char* out,
                          int64_t out_stride, int32_t* n_domains, int32_t* rc, int32_t n_threads);
 
+/* The same with the strings packed back to back: protein p's string (no NUL) is out[out_off[p], out_off[p+1]); out_off has
+ * n_prot + 1 entries.  Proteins are handed to the threads one at a time (long ones do not queue up behind each other).
+ * What a database flush uses: no n_prot x stride scratch to zero and to search for terminators. */
+int reccut_predict_packed(int64_t n_prot, const int32_t* n_res, const int64_t* offs, const int32_t* ci, const int32_t* cj,
+                          const float* prob, double cut1, double cut2, char* out, int64_t out_cap, int64_t* out_off,
+                          int32_t* n_domains, int32_t* rc, int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

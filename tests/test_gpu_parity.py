@@ -339,7 +339,7 @@ def test_fused_groups_large_batch(dd):
     np.testing.assert_array_equal(chunked, plain)
     row = 0
     for s in range(0, n_seq, 37):
-        first = table.owner.index(s)
+        first = list(table.owner).index(s)
         a, b = int(offs[s]), int(offs[s]) + lens[s]
         q = orc.quantize([x[a:b].cpu().numpy() for x in xs], doms[s], [3, 80, 3, 80])
         for k, key in enumerate(q):

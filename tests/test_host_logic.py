@@ -86,8 +86,8 @@ def test_piece_table_layout():
     t = PieceTable([100, 50], [['1-30,61-100', '101-120', '1-100'], ['1-50', '0-10']])
     assert t.n_domains == 3
     assert t.keys == ['1-30,61-100', '1-100', '1-50']
-    assert t.owner == [0, 0, 1]
-    assert t.lengths == [70, 100, 50]
+    assert list(t.owner) == [0, 0, 1]
+    assert list(t.lengths) == [70, 100, 50]
     p = t.pieces
     assert p['row_start'].tolist() == [0, 60, 0, 0]
     assert p['n_rows'].tolist() == [30, 40, 100, 50]
@@ -115,3 +115,81 @@ def test_fingerprint_is_picklable_and_keeps_the_reference_fields():
     assert isinstance(empty.contacts, np.ndarray)
     for name in ('writece', 'reccut', 'scale', 'idct_quant', 'get_doms', 'quantize'):
         assert callable(getattr(fp, name))
+
+
+def _table_python(seq_rows, domains):
+    """PieceTable through the string-by-string Python path (domains.split_domain)."""
+    from dctdomain_amd import PieceTable
+    t = PieceTable.__new__(PieceTable)
+    t.seq_rows = np.ascontiguousarray(np.asarray(seq_rows, dtype=np.int64))
+    t._init_python([d for doms in domains for d in doms], np.array([len(d) for d in domains], dtype=np.int32))
+    return t
+
+
+def _same_table(a, b):
+    assert a.n_domains == b.n_domains
+    assert a.keys == b.keys
+    for name in ('owner', 'source', 'lengths'):
+        assert list(getattr(a, name)) == list(getattr(b, name)), name
+    assert a.pieces.tolist() == b.pieces.tolist()
+
+
+def test_piece_table_c_builder_matches_the_reference_table_and_the_python_rules():
+    """dctfp_build_pieces (the C builder behind PieceTable) against the get_doms table produced by the imported reference
+    (tests/golden/getdoms_golden.json) and against domains.split_domain on seeded random strings that hit every quirk:
+    pieces beginning beyond the sequence (dropped, the next one skipped, the first equal string removed), beg == 0,
+    clipped ends, empty domains, repeated pieces."""
+    from dctdomain_amd import PieceTable
+    with open(os.path.join(gu.GOLD, 'getdoms_golden.json')) as fh:
+        gold = json.load(fh)
+    for row in gold:
+        t = PieceTable([row['L']], [[row['dom']]])
+        rows = [r for p in t.pieces for r in range(int(p['row_start']), int(p['row_start']) + int(p['n_rows']))]
+        assert rows == row['rows'], row
+        if rows:
+            assert t.keys == [row['key']], row
+        else:
+            assert t.n_domains == 0
+    # all golden strings as ONE batch
+    _same_table(PieceTable([r['L'] for r in gold], [[r['dom']] for r in gold]),
+                _table_python([r['L'] for r in gold], [[r['dom']] for r in gold]))
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        n_seq = int(rng.integers(1, 6))
+        lens = [int(rng.integers(1, 120)) for _ in range(n_seq)]
+        doms = []
+        for L in lens:
+            dl = []
+            for _ in range(int(rng.integers(0, 5))):
+                parts = []
+                for _ in range(int(rng.integers(1, 5))):
+                    kind = rng.integers(0, 10)
+                    if kind == 0:
+                        b, e = 0, int(rng.integers(0, L + 20))
+                    elif kind <= 2:
+                        b = int(rng.integers(L, L + 30))
+                        e = b + int(rng.integers(0, 20))
+                    else:
+                        b = int(rng.integers(1, L + 1))
+                        e = int(rng.integers(b - 3 if b > 3 else b, L + 15))
+                    parts.append(f'{b}-{e}')
+                    if rng.random() < 0.25:
+                        parts.append(parts[int(rng.integers(0, len(parts)))])      # a repeated piece
+                dl.append(','.join(parts))
+            doms.append(dl)
+        _same_table(PieceTable(lens, doms), _table_python(lens, doms))
+
+
+def test_piece_table_leaves_odd_strings_to_python():
+    """Whatever is not digits-digits[,...] keeps Python's own semantics: int() accepts blanks, '+', '_'; a malformed piece
+    raises ValueError like the reference's `beg, end = reg.split('-')`."""
+    from dctdomain_amd import PieceTable
+    t = PieceTable([100, 100], [[' 1 - 30', '+5-10', '1_0-2_0'], ['1-100']])
+    assert t.keys == [' 1 - 30', '+5-10', '1_0-2_0', '1-100'] and list(t.lengths) == [30, 6, 11, 100]
+    for bad in ('', '5', '1-2-3', '1-5,', 'a-b'):
+        with pytest.raises(ValueError):
+            PieceTable([100], [[bad]])
+    with pytest.raises(ValueError):
+        PieceTable([100, 50], [['1-5']])           # one domain list per sequence
+    e = PieceTable([10, 10], [[], []])
+    assert e.n_domains == 0 and len(e.pieces) == 0 and e.keys == []

@@ -159,7 +159,7 @@ def _place(torch, layers, offs, s, case):
 
 def _check_goldens(out, table, placed):
     for s, case in placed.items():
-        first = table.owner.index(s)
+        first = list(table.owner).index(s)
         exp = gu.expected(case)
         width = 240 * len(case['layers'])
         for k, key in enumerate(case['keys']):
@@ -172,7 +172,7 @@ def _check_oracle(out, table, layers, offs, lens, doms, sample):
     for s in sample:
         a, b = int(offs[s]), int(offs[s]) + int(lens[s])
         q = orc.quantize([x[a:b].cpu().numpy() for x in layers], doms[s], [3, 80] * len(layers))
-        first = table.owner.index(s)
+        first = list(table.owner).index(s)
         for k, (key, exp) in enumerate(q.items()):
             np.testing.assert_array_equal(out[first + k].astype(np.int64), exp, err_msg=f'seq {s} {key}')
 
