@@ -14,6 +14,7 @@ with the same two callables works (``SyntheticModel`` for tests and benchmarks):
 from __future__ import annotations
 
 import ctypes as C
+from collections.abc import Sequence
 from dataclasses import dataclass, field
 from typing import List
 
@@ -117,18 +118,40 @@ def stitch_embeddings(windows: List[torch.Tensor], overlap: int = OVERLAP) -> to
     return stitch_embeddings_batch([windows], overlap)[0]
 
 
+class _Views(Sequence):
+    """The per-sequence results of a batch as a read-only sequence of tensors: views of ONE allocation, made when asked
+    for (2 000 ``narrow`` calls up front cost more than the kernels of the batch)."""
+
+    def __init__(self, big: torch.Tensor, first, sizes, square: bool):
+        self._big, self._first, self._sizes, self._square = big, first, sizes, square
+
+    def __len__(self):
+        return len(self._sizes)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        n = len(self._sizes)
+        if k < 0:
+            k += n
+        if not 0 <= k < n:
+            raise IndexError(k)
+        a, size = int(self._first[k]), int(self._sizes[k])
+        if self._square:
+            return self._big[a:a + size * size].view(size, size)
+        return self._big[a:a + size]
+
+
 def _float_windows(seq_windows):
     """Flat list of the windows as float32 tensors with contiguous rows + windows per sequence.  The common case (windows
-    straight off the model) costs two attribute reads per window."""
+    straight off the model) costs two C-level passes over the list."""
     flat = [w for windows in seq_windows for w in windows]
-    if any(w.dtype != torch.float32 or w.stride(-1) != 1 or w.dim() != 2 for w in flat):
+    if {w.dtype for w in flat} != {torch.float32} or not all(map(torch.Tensor.is_contiguous, flat)):
         fixed = []
         for w in flat:
-            if w.dim() != 2:
-                raise ValueError(f'a window must be a 2-D tensor, got shape {tuple(w.shape)}')
             if w.dtype != torch.float32:
                 w = w.float()
-            if w.stride(-1) != 1:
+            if w.dim() == 2 and w.stride(-1) != 1:
                 w = w.contiguous()
             fixed.append(w)
         flat = fixed
@@ -145,12 +168,15 @@ def _stitch_sequences(flat, counts, step: int, square: bool, n_cols: int):
     seq_win = np.zeros(n_seq + 1, dtype=np.int64)
     np.cumsum(counts, out=seq_win[1:])
     rows = np.fromiter((w.shape[0] for w in flat), dtype=np.int32, count=n_win)
-    lds = np.fromiter((w.stride(0) for w in flat), dtype=np.int64, count=n_win)
+    numel = np.fromiter(map(torch.Tensor.numel, flat), dtype=np.int64, count=n_win)
     ptrs = np.fromiter(map(torch.Tensor.data_ptr, flat), dtype=np.uint64, count=n_win)
-    if square:
-        lds = np.where(rows > 1, lds, rows)
-    else:
-        lds = np.where(rows > 1, lds, n_cols)
+    width = rows.astype(np.int64) if square else np.int64(n_cols)
+    if not (numel == rows * width).all() or not all(w.dim() == 2 for w in flat[:1]):
+        raise ValueError('a contact window must be square' if square else 'windows of different widths')
+    if all(map(torch.Tensor.is_contiguous, flat)):
+        lds = np.broadcast_to(width, rows.shape).astype(np.int64)
+    else:                   # (row-strided views: the leading dimension of each window)
+        lds = np.fromiter((w.stride(0) if w.shape[0] > 1 else w.shape[1] for w in flat), dtype=np.int64, count=n_win)
     lib = _lib.load()
     sizes = np.empty(n_seq, dtype=np.int64)
     rc = lib.dctfp_stitch_sizes(rows.ctypes.data, seq_win.ctypes.data, n_seq, int(step), 1 if square else 0, sizes.ctypes.data)
@@ -160,39 +186,39 @@ def _stitch_sequences(flat, counts, step: int, square: bool, n_cols: int):
     if square:
         elems = sizes * sizes
         big = torch.zeros(int(elems.sum()), dtype=torch.float32, device=device)      # new_mat = torch.zeros, :143
-        outs = [v.view(n, n) for v, n in zip(torch.split(big, elems.tolist()), sizes.tolist())]
         dst_ld = sizes
+        first = np.zeros(n_seq, dtype=np.int64)
+        np.cumsum(elems[:-1], out=first[1:])
+        dst = np.uint64(big.data_ptr()) + first.astype(np.uint64) * np.uint64(4)
     else:
-        elems = sizes * n_cols
         big = torch.empty((int(sizes.sum()), n_cols), dtype=torch.float32, device=device)
-        outs = list(torch.split(big, sizes.tolist()))
         dst_ld = np.full(n_seq, n_cols, dtype=np.int64)
-    first = np.zeros(n_seq, dtype=np.uint64)
-    np.cumsum(elems[:-1], out=first[1:].view(np.int64))
-    dst = np.uint64(big.data_ptr()) + first * np.uint64(4)
+        first = np.zeros(n_seq, dtype=np.int64)
+        np.cumsum(sizes[:-1], out=first[1:])
+        dst = np.uint64(big.data_ptr()) + first.astype(np.uint64) * np.uint64(4 * n_cols)
     ctx = _lib.get_context(device.index)
     stream = torch.cuda.current_stream(device)
     _lib.check(lib.dctfp_stitch_sequences(ctx.handle, ptrs.ctypes.data, rows.ctypes.data, lds.ctypes.data, seq_win.ctypes.data,
                                           n_seq, dst.ctypes.data, np.ascontiguousarray(dst_ld, dtype=np.int64).ctypes.data,
                                           int(n_cols), int(step), 1 if square else 0, C.c_void_p(stream.cuda_stream)), lib)
-    return outs
+    return _Views(big, first, sizes, square)
 
 
-def stitch_embeddings_batch(seq_windows: List[List[torch.Tensor]], overlap: int = OVERLAP) -> List[torch.Tensor]:
+def stitch_embeddings_batch(seq_windows: List[List[torch.Tensor]], overlap: int = OVERLAP):
     """Same for many sequences: one kernel launch per window index for the whole batch.  The window geometry is worked
-    out in C (``dctfp_stitch_sequences``); the results are views of ONE allocation (keep one and all stay alive)."""
+    out in C (``dctfp_stitch_sequences``); the results come back as a sequence of views of ONE allocation (keep one and
+    all stay alive)."""
     if not seq_windows:
         return []
     flat, counts = _float_windows(seq_windows)
     if (counts < 1).any():
         raise ValueError('a sequence without windows')
-    n_cols = flat[0].shape[1]
-    if any(w.shape[1] != n_cols for w in flat):
-        raise ValueError('windows of different widths')
-    return _stitch_sequences(flat, counts, overlap, False, n_cols)
+    if flat[0].dim() != 2:
+        raise ValueError(f'a window must be a 2-D tensor, got shape {tuple(flat[0].shape)}')
+    return _stitch_sequences(flat, counts, overlap, False, flat[0].shape[1])
 
 
-def stitch_contacts_batch(seq_windows: List[List[torch.Tensor]], inc: int) -> List[torch.Tensor]:
+def stitch_contacts_batch(seq_windows: List[List[torch.Tensor]], inc: int):
     """``combine_contacts`` applied window after window (src/embedding.py:123-150, :188): window i's
     map lands at offset ``inc * i``; the part overlapping the running map is averaged."""
     if not seq_windows:
@@ -200,8 +226,6 @@ def stitch_contacts_batch(seq_windows: List[List[torch.Tensor]], inc: int) -> Li
     flat, counts = _float_windows(seq_windows)
     if (counts < 1).any():
         raise ValueError('a sequence without windows')
-    if any(w.shape[0] != w.shape[1] for w in flat):
-        raise ValueError('a contact window must be square')
     return _stitch_sequences(flat, counts, inc, True, 1)
 
 
