@@ -283,6 +283,7 @@ __device__ inline void scale_pack3(const double (&f)[2], const InvTab<3>& inv, b
     const bool den_inf = den == INFINITY;              // finite / inf = 0
     double mid = 0.0;
     code = 0;
+    bool any_nan = false;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const double num = y[j] - mn;
@@ -292,9 +293,15 @@ __device__ inline void scale_pack3(const double (&f)[2], const InvTab<3>& inv, b
         st = is0 ? (zero_ok ? 0u : 3u) : st;
         st = (bad || num != num) ? 3u : st;
         mid = (st == 2u) ? num : mid;
+        // A NaN row is stored as state 2 with t = NaN: states 2 and 3 never meet in one channel (a channel with a finite,
+        // positive range has the states 0, 1, 2 only; any other range leaves 0 and 3 only), and the flush's unpacking loses
+        // its NaN case (5 instead of 9 instructions per value).
+        any_nan |= st == 3u;
+        st = st == 3u ? 2u : st;
         code |= st << (2 * j);
     }
     t = mid / den;
+    t = any_nan ? __builtin_nan("") : t;
     if (pad) {
         t = 0.0;
         code = 0;
@@ -329,16 +336,14 @@ __device__ inline double unpack_y(unsigned st, double t) {
     return __longlong_as_double((long long)v);
 }
 
-// The same from a state word already shifted to the row's bit pair, the channel's byte at a static position: masks instead
-// of compares and selects (7 instructions; the flush of the walk kernel unpacks 2 x 4 x 128 values per job and wave).
-//   st = 0 -> 0, 1 -> 1.0, 2 -> t, 3 -> NaN (t's bits with exponent and quiet bit forced)
+// The same for the walk kernel's slots, from a state word with the channel's byte at a static position: masks instead of
+// compares and selects (the flush unpacks 2 x 4 x 128 values per job and wave).
+//   st = 0 -> 0, 1 -> 1.0, 2 -> t (a NaN row carries t = NaN, see scale_pack3): two bit-field extracts, an and, an and-or, an and
 __device__ inline double unpack_bits(uint32_t word, int pos, double t) {
     const int m1 = __builtin_amdgcn_sbfe((int)word, (unsigned)pos, 1u);      // -1 where bit 0 of the state is set
     const int m2 = __builtin_amdgcn_sbfe((int)word, (unsigned)pos + 1u, 1u);  // -1 where bit 1 is set
     const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
-    const uint32_t k = (uint32_t)m1 & 0x3FF00000u;
-    const uint32_t k2 = ((uint32_t)(m1 & m2) & 0x7FF80000u) | k;
-    const uint32_t hi = ((uint32_t)(tb >> 32) & (uint32_t)m2) | k2;
+    const uint32_t hi = ((uint32_t)(tb >> 32) & (uint32_t)m2) | ((uint32_t)m1 & 0x3FF00000u);
     const uint32_t lo = (uint32_t)tb & (uint32_t)m2;
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
@@ -937,7 +942,7 @@ __global__ __launch_bounds__(256) void stage_b_finish_kernel(const double* __res
 //           lanes 0..31 stream channels [128 w, 128 w + 128) of every row, lanes 32..63 their mirror images (two 512-byte
 //           segments per row), UNROLL rows in flight, cosines through the scalar cache.  No barrier per job -- the
 //           epilogue of a job is wave-private.
-//   flush : every G jobs (or at the end of the run), stage B in even / odd halves (see "flush" in the kernel): with
+//   flush : every G jobs (or at the end of the run), no workgroup barrier (tickets, see its end); stage B in even / odd halves (see "flush" in the kernel): with
 //           u = y[d] + y[D-1-d], v = y[d] - y[D-1-d]: ZE[c] = sum u E[d][c], ZO[c] = sum v O[d][c] over the D/2 pairs and
 //           the m/2 left columns, Z[c] = ZE + ZO, Z[m-1-c] = ZE - ZO.  v_mfma_f64_4x4x4_4b_f64 (measured 16.8 cycles,
 //           75 TFLOP/s with 8 independent accumulators; tools/microbench/mfma_f64_probe.hip): per block b = (lane >> 2) & 3
@@ -1031,9 +1036,10 @@ struct Run {
 
 // Instrumented build (tools/walk_timeline.py; never the shipped library): every wave adds the time (s_memrealtime: the
 // constant 100 MHz counter -- the shader clock moves with the power management, by 20 % between variants) it
-// spends per phase to degenerate[1 + phase] -- 0 stream (job record -> last row accumulated), 1 epilogue, 2 flush
-// contraction (unpack + MFMA), 3 wait at the barrier before the cross-wave sum, 4 cross-wave sum + int8, 5 wait at the
-// barrier that frees the slots, 6 everything else, 7 wave lifetime; 8 waves, 9 jobs, 10 flushes.
+// spends per phase to degenerate[1 + phase] -- 0 stream (job record -> last row accumulated), 1 epilogue (+ the wait for the
+// slots of the last flush group, if any), 2 flush contraction (unpack + MFMA), 3 ticket, 4 wait for the last arrival + cross-wave
+// sum + int8 (the last arrivals only), 5 unused since round 4 (was: the barrier that freed the slots), 6 everything else,
+// 7 wave lifetime; 8 waves, 9 jobs, 10 flushes.
 #ifdef DCTFP_WALK_TIMELINE
 #define DCTFP_TL_DECL                                   \
     uint64_t tl_prev = __builtin_amdgcn_s_memrealtime();    \
@@ -1066,6 +1072,15 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
     static_assert(3 * NT * 16 <= WCH, "partial Z block must fit the slot it reuses");
     __shared__ double lds_t[S][G][WCH];
     __shared__ uint32_t lds_c[S][G][WCH / 4];
+    // The flush has no workgroup barrier (see its end): `lds_arrived` counts the waves that have stored their partial blocks,
+    // `lds_done` the jobs whose rows are written -- over all flushes of the workgroup so far.
+    __shared__ uint32_t lds_arrived, lds_done;
+    uint32_t flush_seq = 0, done_expected = 0;
+    if (threadIdx.x == 0) {
+        lds_arrived = 0;
+        lds_done = 0;
+    }
+    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1388,6 +1403,11 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 }
                 int sl = lane;
                 if constexpr (MA) asm volatile("" : "+v"(sl));
+                if (pending == 0 && done_expected != 0) {  // first write of a flush group: the rows of the last one must be out
+                    while (__hip_atomic_load(&lds_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != done_expected)
+                        __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
                 *reinterpret_cast<v4d*>(&lds_t[wave][pending][VEC * sl]) = (v4d){tv[0], tv[1], tv[2], tv[3]};
                 lds_c[wave][pending][sl] = c4;
             }
@@ -1533,12 +1553,40 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                     }
                 }
             };
-            __syncthreads();
-            DCTFP_TL_MARK(3);
-            for (uint32_t g = (uint32_t)wave; g < pending; g += S) finish_job(g);
-            DCTFP_TL_MARK(4);
-            __syncthreads();  // the slots are free again
-            DCTFP_TL_MARK(5);
+            // No workgroup barrier.  A wave that has stored its partial blocks draws a ticket and goes on streaming; the LAST
+            // min(S, pending) waves to arrive -- the ones nobody would have to wait for -- write the rows, each one job
+            // (g, g + nf, ...), once every wave has arrived.  The sum over the partial blocks runs in wave order whoever does
+            // it, so the bytes do not depend on the order of arrival.  The slots are reused only after `lds_done` says the rows
+            // are out (checked before the first write of the next group, a whole job's stream later), so the waves of a
+            // workgroup may drift apart by up to a job before anyone waits for anyone -- and no wave draws a ticket of flush
+            // n + 1 before every wave has drawn its ticket of flush n (its first write of group n + 1 waits for rows that the
+            // last arrival of flush n has to release).
+            // Round 4 measured what that buys: +0.3 % (c4) .. +0.4 % (C2).  The waves DID wait 9-17 % of their time at the two
+            // barriers this replaces (profiles/r03/wave_wait_probe_shipped_kernel.txt) -- and the rate does not care: what a
+            // wave waits for there is issue time that the other waves of its SIMD are using (profiles/r04/experiments/).
+            {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                uint32_t ticket = 0;
+                if (lane == 0) ticket = __hip_atomic_fetch_add(&lds_arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+                const uint32_t idx = ticket - (uint32_t)S * flush_seq;       // my place among the arrivals of this flush
+                const uint32_t nf = pending < (uint32_t)S ? pending : (uint32_t)S;
+                DCTFP_TL_MARK(3);
+                if (idx >= (uint32_t)S - nf) {
+                    const uint32_t all = (uint32_t)S * (flush_seq + 1u);
+                    while (__hip_atomic_load(&lds_arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != all)
+                        __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    for (uint32_t g = idx - ((uint32_t)S - nf); g < pending; g += nf) {
+                        finish_job(g);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_fetch_add(&lds_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                ++flush_seq;
+                done_expected += pending;
+                DCTFP_TL_MARK(4);
+            }
             group_job += pending;
             pending = 0;
         }

@@ -274,6 +274,8 @@ int dctfp_crash_handler(int enable);
  *   "ab_group"     walk kernel: jobs per stage-B flush (0 = auto = 4, 3, 4)
  *   "ab_unroll"    walk kernel: rows in flight per wave (0 = 8; 4, 6, 8, 12, 16; float32 rows only)
  *   "ab_run_jobs"  walk kernel: jobs per workgroup (0 = by the bytes per job and the size of the call)
+ *   "ab_align"     walk kernel: walks to look ahead for a workgroup whose job count is a multiple of the flush group, so that
+ *                  its last flush is a full one (default 2; 0 = off)
  *   "ab_taper"     walk kernel: the jobs of the last N quarter-rounds of workgroups go out in workgroups of one flush
  *                  group, so that the launch ends evenly (default 4 = one round; 0 = off)
  *   "ab_mfma_a"    walk kernel, fused walks of float32 rows: 1 = the multiply-adds of stage A as v_mfma_f64_4x4x4 on
