@@ -149,6 +149,7 @@ struct StEntry {  // stage-B basis  St[d][c] (ldy x cp), zero padded
     double* dev = nullptr;
     double* frag = nullptr;  // even/odd halves of the basis in MFMA-fragment order (walk_ab_kernel), `frag_groups` 16-pair groups
     int frag_groups = 0;
+    double* fragp = nullptr; // the plain basis in MFMA-fragment order (walk_gen_kernel), made when that kernel first wants it
     int ldy = 0, cp = 0;
     uint64_t last_use = 0;
 };
@@ -282,6 +283,7 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
         HIP_TRY(hipDeviceSynchronize());
         (void)hipFree(victim->second.dev);
         if (victim->second.frag) (void)hipFree(victim->second.frag);
+        if (victim->second.fragp) (void)hipFree(victim->second.fragp);
         ctx->st_cache.erase(victim);
     }
     const int ldy = (int)align_up((size_t)n_cols, 32);
@@ -362,6 +364,33 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
     auto ins = ctx->st_cache.emplace(key, e);
     dev_guard.armed = false;
     *out = &ins.first->second;
+    return DCTFP_OK;
+}
+
+// The plain basis of (D, m) in the fragment order of walk_gen_kernel, from the row-major table get_st made:
+//   fragp[(q NT + c) 64 + lane] = St[4 q + (lane >> 4)][16 c + (lane & 15)],  zero beyond D;  q < ceil(D / 4) + 64
+// (the kernel's waves stop at the last k-step that holds a channel; the slack keeps a wave's base address inside the table).
+int get_st_plain(dctfp_ctx* ctx, StEntry* st, int n_cols) {
+    if (st->fragp) return DCTFP_OK;
+    const int nt = st->cp / 16, steps = (n_cols + 3) / 4 + 64;
+    std::vector<double> host((size_t)st->ldy * st->cp);
+    HIP_TRY(hipMemcpy(host.data(), st->dev, host.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> fr((size_t)steps * nt * 64, 0.0);
+    for (int q = 0; q < steps; ++q)
+        for (int c = 0; c < nt; ++c)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int d = 4 * q + (lane >> 4), col = 16 * c + (lane & 15);
+                if (d < n_cols) fr[((size_t)q * nt + c) * 64 + lane] = host[(size_t)d * st->cp + col];
+            }
+    double* dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&dev, fr.size() * sizeof(double)));
+    const hipError_t err = hipMemcpy(dev, fr.data(), fr.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        (void)hipFree(dev);
+        return fail(DCTFP_ERR_HIP, "St plain fragments: %s", hipGetErrorString(err));
+    }
+    st->fragp = dev;
+    (void)ctx;
     return DCTFP_OK;
 }
 
@@ -650,6 +679,67 @@ int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fuse
     return fail(DCTFP_ERR_INVALID, "walk kernel: no build for %d waves x %d jobs per flush", s, g);
 }
 
+// walk_gen_kernel: the shapes walk_ab_kernel does not take.
+struct GParams {
+    const JobA* jobs;
+    const JobB* jobb;
+    const Run* runs;
+    const PieceA* pieces;
+    const double* stp;
+    int8_t* out;
+    int n_cols;
+    int64_t ld;
+    int m;
+    int n_slots;
+    unsigned long long* degenerate;
+    unsigned grid;
+    unsigned waves;
+    size_t lds_bytes;
+    hipStream_t stream;
+};
+
+constexpr size_t kGenLdsBudget = 150 * 1024;  // of the 160 KB of a CU
+
+// LDS of one slot: Y'[N][CH] float64; the partial Z blocks [S][N][cp] reuse it unless a wave's columns are too few
+size_t gen_slot_bytes(int n, int m, int waves, int vec) {
+    const size_t ch = (size_t)waves * 64 * vec, cp = align_up((size_t)m, 16);
+    return ((size_t)n * ch + (cp <= (size_t)64 * vec ? 0 : (size_t)waves * n * cp)) * sizeof(double);
+}
+
+template <typename T, int N, int VEC>
+int launch_gen_impl(const GParams& p) {
+    static const InvTab<N> inv = make_inv<N>();
+    static bool attr_set = false;
+    if (!attr_set) {  // dynamic LDS above 64 KB has to be asked for, once per kernel
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&walk_gen_kernel<T, N, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kGenLdsBudget + 1024)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((walk_gen_kernel<T, N, VEC>), dim3(p.grid), dim3(p.waves * 64), p.lds_bytes, p.stream, p.jobs, p.jobb, p.runs,
+                       p.pieces, p.stp, p.out, p.n_cols, p.ld, p.m, p.n_slots, inv, p.degenerate);
+    return DCTFP_OK;
+}
+
+template <typename T, int VEC>
+int launch_gen_n(const GParams& p, int n) {
+    switch (n) {
+        case 2: return launch_gen_impl<T, 2, VEC>(p);
+        case 3: return launch_gen_impl<T, 3, VEC>(p);
+        case 4: return launch_gen_impl<T, 4, VEC>(p);
+        case 5: return launch_gen_impl<T, 5, VEC>(p);
+        case 6: return launch_gen_impl<T, 6, VEC>(p);
+        case 7: return launch_gen_impl<T, 7, VEC>(p);
+        case 8: return launch_gen_impl<T, 8, VEC>(p);
+        default: return fail(DCTFP_ERR_INVALID, "walk_gen_kernel: n = %d", n);
+    }
+}
+
+int launch_gen(const GParams& p, int dtype, int vec, int n) {
+    if (dtype == DCTFP_F32) return vec == 4 ? launch_gen_n<float, 4>(p, n) : launch_gen_n<float, 1>(p, n);
+    if (dtype == DCTFP_F64) return vec == 2 ? launch_gen_n<double, 2>(p, n) : launch_gen_n<double, 1>(p, n);
+    return fail(DCTFP_ERR_INVALID, "walk_gen_kernel: float32 or float64 rows");
+}
+
 int prof_begin(dctfp_ctx* ctx, int which, hipStream_t s, EventPair** ep) {
     *ep = nullptr;
     if (!ctx->opt_profile) return DCTFP_OK;
@@ -746,6 +836,7 @@ int dctfp_destroy(dctfp_ctx* ctx) try {
     for (auto& kv : ctx->st_cache) {
         (void)hipFree(kv.second.dev);
         if (kv.second.frag) (void)hipFree(kv.second.frag);
+        if (kv.second.fragp) (void)hipFree(kv.second.fragp);
     }
     for (auto& sl : ctx->basis_slabs) (void)hipFree(sl.dev);
     if (ctx->degenerate) (void)hipFree(ctx->degenerate);
@@ -960,7 +1051,21 @@ constexpr uint32_t kWalkMaxRows = 8192;  // longest domain a wave of the walk ke
 
 // Shapes the walk kernel takes (the rest of its conditions -- alignment, job count -- are judged per call in quantize_impl).
 bool walk_shape(const dctfp_layer& ly) {
-    return ly.n_keep == 3 && ly.m_keep > 64 && ly.m_keep <= 80 && ly.dtype != DCTFP_F64 && ly.n_cols >= 512 && ly.n_cols <= 2560;
+#ifdef DCTFP_GEN_ALL
+    return false;
+#endif
+    if (ly.dtype == DCTFP_F64) return false;  // float64 rows: the general kernel (6.73 against 5.73 TB/s through this one's double build)
+    return ly.n_keep == 3 && ly.m_keep > 64 && ly.m_keep <= 80 && ly.n_cols >= 512 && ly.n_cols <= 2560 && ly.n_cols % 4 == 0;
+}
+
+// Shapes the general walk kernel (walk_gen_kernel) takes: float32 / float64 rows, n = 2 .. 8, whatever width and m fit the LDS
+// with one slot at 4 (float32) / 2 (float64) channels per lane -- the widest layout; an unaligned layer needs 1 channel per
+// lane and is judged again per call.
+bool gen_shape(const dctfp_layer& ly) {
+    if (ly.n_keep < 2 || ly.m_keep < 2 || (ly.dtype != DCTFP_F32 && ly.dtype != DCTFP_F64)) return false;
+    const int vec = ly.dtype == DCTFP_F32 ? 4 : 2;
+    const int waves = (ly.n_cols + 64 * vec - 1) / (64 * vec);
+    return waves <= 16 && gen_slot_bytes(ly.n_keep, ly.m_keep, waves, vec) + 64 <= kGenLdsBudget;
 }
 
 // dctfp_quantize proper.  `out_row` (optional): the output row of every domain of THIS piece table (a call that
@@ -1131,9 +1236,47 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
         for (size_t i = 0; i < fresh.size(); ++i) hbt[i] = fresh[i];
 
         const int ldy_pre = (int)align_up((size_t)g.n_cols, 32);
-        // (a small call wants parallelism, not fewer bytes: every job on its own workgroups)
-        const bool fuse = !trivial && n_groups > 0 && n_jobs >= 64;
+        // 16 bytes per lane where every row of every sequence allows it
         bool vec_ok = true;
+        for (int li = 0; li < ng && vec_ok; ++li)
+            for (int32_t sq = 0; sq < n_seq && vec_ok; ++sq)
+                if (seq_rows[sq] > 0 && !aligned16(layers[l0 + li].seq_data[sq])) vec_ok = false;
+        const int vec_want = (int)(16 / esz);  // 16 bytes per lane
+        if (((size_t)g.ld * esz) % 16 != 0 || g.n_cols % vec_want != 0) vec_ok = false;
+        // ---- which kernels.  The walk kernel (stage A + B in one launch, nothing but int8 written) takes the production
+        // shapes: n = 3, 64 < m <= 80 (five 16-column groups), rows read 4 channels per lane, 512 <= D <= 2560, no giant domain
+        // (a wave streams all rows of its channels).  Every other shape of float32 / float64 rows that fits the LDS goes to the
+        // general walk kernel (round 4); the rest -- and calls too small to fill the chip -- run stage A -> Y' -> stage B.
+        // (rows are addressed through a 32-bit buffer offset: a piece of at most kWalkMaxRows rows stays below 2^31 bytes)
+        const bool rows_ok = max_len_all <= kWalkMaxRows && (size_t)g.ld * esz <= ((size_t)1 << 31) / kWalkMaxRows && ctx->opt_stage_b == 1;
+        const bool walk_ok = !trivial && walk_shape(g) && vec_ok && rows_ok;
+        const bool use_walk = walk_ok && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 256));
+        int gen_vec = 0, gen_waves = 0, gen_slots = 0;
+        if (!trivial && !walk_ok && rows_ok && n >= 2 && m >= 2 && (g.dtype == DCTFP_F32 || g.dtype == DCTFP_F64)) {
+            gen_vec = vec_ok ? vec_want : 1;
+            gen_waves = (g.n_cols + 64 * gen_vec - 1) / (64 * gen_vec);
+            const size_t slot = gen_slot_bytes(n, m, gen_waves, gen_vec);
+            gen_slots = gen_waves <= 16 && slot + 64 <= kGenLdsBudget ? 1 : 0;
+            // A second slot (a wave writes the next job's Y' while the last arrival of this one still sums) only where it
+            // costs no workgroup per CU: resident workgroups hide the end of a job (epilogue, contraction, row sums), and a
+            // wave reaches its next write a whole job's stream after the last one anyway.
+            if (gen_slots == 1) {
+                const size_t by_waves = std::max<size_t>(1, 20 / (size_t)gen_waves);   // (the kernel's builds hold 5 .. 7 waves per SIMD)
+                const size_t one = std::min(by_waves, kGenLdsBudget / (slot + 64)), two = std::min(by_waves, kGenLdsBudget / (2 * slot + 64));
+                if (two >= one) gen_slots = 2;
+            }
+        }
+        // (a shape whose slot leaves fewer than eight waves resident per CU -- [8, 128] at D = 1280: one workgroup of five -- streams
+        //  at 3.8 TB/s there against 5.4 through the two kernels: only when asked for)
+        const int64_t gen_resident = gen_slots > 0 ? gen_waves * std::min<int64_t>(std::max<int64_t>(1, 20 / gen_waves), (int64_t)(kGenLdsBudget / (gen_slots * gen_slot_bytes(n, m, gen_waves, gen_vec) + 64))) : 0;
+        // (... and it streams every job on its own: where proteins come as parts + whole protein, the fused stage A of the two
+        //  kernels reads the rows once -- 3.6-4.7 against 2.1-2.3 TB/s on the c4 / c5 mixes at [5, 44] / [3, 85] / [4, 80],
+        //  tools/gen_probe.py; on whole-protein batches the general kernel is 2-6 % ahead)
+        const bool would_fuse = ctx->opt_fuse && n_groups > 0;
+        const bool use_gen = gen_slots > 0 && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 256 && gen_resident >= 8 && !would_fuse));
+        // (a small call wants parallelism, not fewer bytes: every job on its own workgroups; the general walk kernel streams
+        //  every job on its own)
+        const bool fuse = !trivial && n_groups > 0 && n_jobs >= 64 && !use_gen;
         for (int li = 0; li < ng; ++li) {
             const dctfp_layer& ly = layers[l0 + li];
             for (int64_t d = 0; d < n_domains; ++d) {
@@ -1166,35 +1309,26 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
                 o.reserved = 0;
                 t0 += (uint32_t)pc.n_rows;
             }
-            for (int32_t s = 0; s < n_seq; ++s)
-                if (seq_rows[s] > 0 && !aligned16(ly.seq_data[s])) vec_ok = false;
         }
-        const int vec_want = (int)(16 / esz);  // 16 bytes per lane
-        if (((size_t)g.ld * esz) % 16 != 0 || g.n_cols % vec_want != 0) vec_ok = false;
         int vec = vec_ok ? vec_want : 1;
         // Fused walks of half-precision rows: 8 channels per lane mean two accumulator sets of 8 -- 27..37 registers per lane
         // spilled, and scratch writes beside the row stream cost far more than their bytes (the c5 mix in float16 took 19 ms
         // against 12.6 in float32).  4 channels per lane (8-byte loads) fit the registers.
         if (fuse && n == 3 && vec == 8) vec = 4;
 
-        // ---- which kernels.  The walk kernel (stage A + B in one launch, nothing but int8 written) takes the
-        // production shapes: n = 3, 64 < m <= 80 (five 16-column groups), float32 / float16 / bfloat16 rows read 4 channels per lane,
-        // 512 <= D <= 2560, no giant domain
-        // (a wave streams all rows of its channels).  Everything else runs stage A -> Y' -> stage B.
-        const bool half_rows = g.dtype == DCTFP_F16 || g.dtype == DCTFP_BF16;  // (their `vec` is 8, or 4 for fused walks: the walk kernel reads 4)
-        // (rows are addressed through a 32-bit buffer offset: a piece of at most kWalkMaxRows rows stays below 2^31 bytes)
-        const bool walk_ok = !trivial && walk_shape(g) && ((g.dtype == DCTFP_F32 && vec == 4) || (half_rows && vec >= 4)) &&
-                             max_len_all <= kWalkMaxRows && (size_t)g.ld * esz <= ((size_t)1 << 31) / kWalkMaxRows && ctx->opt_stage_b == 1;
         // Measured (profiles/r02): the walk kernel wins at every width it takes -- D = 2560 (10-wave workgroups, one per CU)
         // since its flush contracts the even and odd halves of the basis apart: 5.3 against 4.9-5.25 TB/s on config 4.
         // A small call (a protein at a time, the reference's calling pattern) is latency-bound: there the two-kernel path,
         // which spreads one job over slabs x 8 waves, finishes first.
-        const bool use_walk = walk_ok && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 256));
         // walks of ALL jobs (walk kernel) -- the two-kernel path builds its walks per chunk below
         int64_t n_walks = 0, n_runs = 0;
         int walk_s = 0, walk_g = 0;
-        if (use_walk) {
-            walk_s = g.n_cols <= 768 ? 3 : (g.n_cols <= 1280 ? 5 : 10);
+        // workgroups of the kernel the chip holds at once, per CU (LDS: 5 / 3 / 1 at 3 / 5 / 10 waves of the walk kernel)
+        int64_t wg_per_cu = 1;
+        if (use_walk || use_gen) {
+            walk_s = use_gen ? gen_waves : (g.n_cols <= 768 ? 3 : (g.n_cols <= 1280 ? 5 : 10));
+            wg_per_cu = use_gen ? std::max<int64_t>(1, std::min<int64_t>(20 / gen_waves, (int64_t)(kGenLdsBudget / (gen_slots * gen_slot_bytes(n, m, gen_waves, gen_vec) + 64))))
+                                : (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));
             // jobs per flush: 4 = the rows of an MFMA tile (a flush costs the same MFMAs for 1..4 jobs)
             walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : 4;
             for (int64_t j = 0; j < n_jobs;) {
@@ -1228,9 +1362,8 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
                 //  jobs per workgroup, 4.85 with one)
                 const int64_t job_rows = rows * (int64_t)esz / 4 / std::max<int64_t>(1, n_domains);  // whole-protein jobs of fused walks stream nothing
                 const int64_t by_rows = job_rows >= 384 ? 1 : 4 * walk_g;
-                if (ctx->opt_ab_longest_first == 0) longest_first = by_rows >= walk_g && walk_s == 10;
-                // workgroups the chip holds at once (LDS: 5 / 3 / 1 per CU at 3 / 5 / 10 waves)
-                const int64_t slots = (int64_t)ctx->n_cu * (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));
+                if (ctx->opt_ab_longest_first == 0) longest_first = by_rows >= walk_g && walk_s == 10 && !use_gen;
+                const int64_t slots = (int64_t)ctx->n_cu * wg_per_cu;
                 if (n_jobs <= 6 * slots * by_rows) {
                     // fewer than a handful of rounds at that size: ONE round of equal workgroups instead (a second, partly
                     // filled round costs as much as a full one: 1 024 whole-protein jobs 509 us as 1 024 workgroups, 477 as 512)
@@ -1247,7 +1380,7 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             // therefore go out in runs of one flush group: four times as many workgroups, a quarter as long.
             int64_t taper_from = n_jobs;  // runs that start at or after this job are short
             if (want > walk_g && ctx->opt_ab_taper) {
-                const int64_t slots = (int64_t)ctx->n_cu * (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));
+                const int64_t slots = (int64_t)ctx->n_cu * wg_per_cu;
                 taper_from = std::max<int64_t>(0, n_jobs - slots * want * ctx->opt_ab_taper / 4);
             }
             int64_t jobs_done = 0;
@@ -1325,7 +1458,7 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
         const int n_slabs = (ldy_pre + 64 * vec - 1) / (64 * vec);
         int slots = 1;
         int64_t sub = 1;
-        if (!trivial && !use_walk) {
+        if (!trivial && !use_walk && !use_gen) {
             const int64_t budget_jobs = std::max<int64_t>(1, (int64_t)(((size_t)ctx->opt_ws_mb << 20) / job_bytes));
             if (ctx->opt_overlap > 1 && n_jobs >= 2048 && budget_jobs >= 2048) slots = (int)std::min<int64_t>(ctx->opt_overlap, kMaxSlots);
             int64_t max_group = 1;
@@ -1468,8 +1601,45 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
         // tables cached by an earlier call may have been filled on another stream
         if (ctx->basis_valid && ctx->basis_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_basis, 0));
 
-        ctx->last_path = use_walk ? 2 : 1;
-        ctx->walk_launches += use_walk ? 1 : 0;
+        ctx->last_path = (use_walk || use_gen) ? 2 : 1;
+        ctx->walk_launches += (use_walk || use_gen) ? 1 : 0;
+        if (use_gen) {
+            // one launch of the general walk kernel: stage A + stage B per workgroup, int8 out
+            rc = get_st_plain(ctx, st, g.n_cols);
+            if (rc) return rc;
+            EventPair* ep = nullptr;
+            rc = prof_begin(ctx, 0, stream, &ep);
+            if (rc) return rc;
+            GParams gp;
+            gp.jobs = dja;
+            gp.jobb = djb;
+            gp.runs = drun;
+            gp.pieces = dpc;
+            gp.stp = st->fragp;
+            gp.out = out;
+            gp.n_cols = g.n_cols;
+            gp.ld = g.ld;
+            gp.m = m;
+            gp.n_slots = gen_slots;
+            gp.degenerate = ctx->degenerate;
+            gp.grid = (unsigned)n_runs;
+            gp.waves = (unsigned)gen_waves;
+            gp.lds_bytes = (size_t)gen_slots * gen_slot_bytes(n, m, gen_waves, gen_vec) + 64;
+            gp.stream = stream;
+            rc = launch_gen(gp, g.dtype, gen_vec, n);
+            if (rc) return rc;
+            HIP_TRY(hipGetLastError());
+            rc = prof_end(ep, stream);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ctx->ev_tab_free[buf], stream));
+            ctx->tab_busy[buf] = true;
+            if (zero_copy) {  // the kernels read the staging buffer itself: it is free again after them
+                HIP_TRY(hipEventRecord(stg.ev, stream));
+                stg.pending = true;
+            }
+            l0 = l1;
+            continue;
+        }
         if (use_walk) {
             // one launch: stage A + stage B per workgroup, int8 out
             EventPair* ep = nullptr;
@@ -1663,7 +1833,7 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
     // kernel: such domains are cut out into a call of their own (two-kernel path), everything else stays where it was.
     // Only when every layer has the walk kernel's shape and the rest of the call is large enough to be sent there.
     bool all_walk = ctx->opt_path != 1;
-    for (int32_t l = 0; l < n_layers && all_walk; ++l) all_walk = walk_shape(layers[l]);
+    for (int32_t l = 0; l < n_layers && all_walk; ++l) all_walk = walk_shape(layers[l]) || gen_shape(layers[l]);
     if (all_walk && n_domains * n_layers >= 256) {
         std::vector<uint32_t> len((size_t)n_domains, 0);
         bool table_ok = true;

@@ -179,6 +179,49 @@ void emulate_stage_a(const std::string& name, dim3 grid, void** a) {
     }
 }
 
+// walk_gen_kernel (the general walk kernel): every job of every run streams its pieces, reads its cosine table, the plain
+// fragment table up to the last k-step that holds a channel, and writes its n x m block.
+void emulate_walk_gen(const std::string& name, dim3 grid, dim3 block, size_t shmem, void** a) {
+    const JobA* jobs = *(const JobA**)a[0];
+    const JobB* jobb = *(const JobB**)a[1];
+    const Run* runs = *(const Run**)a[2];
+    const PieceA* pieces = *(const PieceA**)a[3];
+    const double* stp = *(const double**)a[4];
+    int8_t* out = *(int8_t**)a[5];
+    const int n_cols = *(int*)a[6];
+    const int64_t ld = *(int64_t*)a[7];
+    const int m = *(int*)a[8];
+    const int n_slots = *(int*)a[9];
+    const size_t esz = elem_size(name, "walk_gen_kernel");
+    const int n = template_int(name, "walk_gen_kernel", 0), vec = template_int(name, "walk_gen_kernel", 1);
+    const int waves = (int)(block.x / 64), nt = (m + 15) / 16;
+    if (block.x % 64 || waves * 64 * vec < n_cols || n_cols % vec || n_slots < 1 || n_slots > 2 ||
+        shmem < (size_t)n_slots * ((size_t)n * waves * 64 * vec + (nt * 16 <= 64 * vec ? 0 : (size_t)waves * n * nt * 16)) * 8 + 16 || shmem > 160 * 1024) {
+        fprintf(stderr, "stub: walk_gen_kernel launch shape: %d waves x %d channels per lane for D = %d, %d slots, %zu bytes of LDS\n", waves, vec, n_cols, n_slots, shmem);
+        abort();
+    }
+    touch(stp, (size_t)((n_cols + 3) / 4) * nt * 64 * sizeof(double));
+    ++g_walk_launches;
+    for (unsigned b = 0; b < grid.x; ++b) {
+        const Run run = runs[b];
+        for (uint32_t j = 0; j < run.n_jobs; ++j) {
+            const JobA job = jobs[run.job_begin + j];
+            uint32_t rows = 0;
+            for (uint32_t p = 0; p < job.n_pieces; ++p) {
+                const PieceA pc = pieces[job.piece_begin + p];
+                if (pc.n_rows == 0 || pc.t0 != rows) { fprintf(stderr, "stub: piece table of job %u broken\n", run.job_begin + j); abort(); }
+                touch(pc.ptr, (size_t)n_cols * esz);
+                touch((const char*)pc.ptr + (size_t)(pc.n_rows - 1) * (size_t)ld * esz, (size_t)n_cols * esz);
+                touch(job.basis + (size_t)pc.t0 * (n - 1), (size_t)pc.n_rows * (n - 1) * sizeof(double));
+                rows += pc.n_rows;
+            }
+            if (rows != job.n_rows || (int)rows < n) { fprintf(stderr, "stub: job %u has %u rows, its pieces %u\n", run.job_begin + j, job.n_rows, rows); abort(); }
+            touch_w(out + jobb[run.job_begin + j].out_off, (size_t)n * m);
+            ++g_jobs_walked;
+        }
+    }
+}
+
 void emulate_basis(dim3 grid, void** a) {
     const BasisJob* tabs = *(const BasisJob**)a[0];
     const int nk = *(int*)a[1];
@@ -250,12 +293,14 @@ hipError_t __hipPopCallConfiguration(dim3* grid, dim3* block, size_t* shmem, hip
     *grid = g_grid; *block = g_block; *shmem = g_shmem; *stream = g_stream;
     return hipSuccess;
 }
-hipError_t hipLaunchKernel(const void* fn, dim3 grid, dim3 block, void** args, size_t, hipStream_t) {
+hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipLaunchKernel(const void* fn, dim3 grid, dim3 block, void** args, size_t shmem, hipStream_t) {
     const auto it = names().find(fn);
     if (it == names().end()) { fprintf(stderr, "stub: launch of an unregistered kernel\n"); abort(); }
     const std::string& n = it->second;
     if (grid.x == 0 || grid.y == 0 || block.x == 0 || block.x > 1024) { fprintf(stderr, "stub: bad launch shape of %s\n", n.c_str()); abort(); }
-    if (n.find("walk_ab_kernel") != std::string::npos) emulate_walk(n, grid, args);
+    if (n.find("walk_gen_kernel") != std::string::npos) emulate_walk_gen(n, grid, block, shmem, args);
+    else if (n.find("walk_ab_kernel") != std::string::npos) emulate_walk(n, grid, args);
     else if (n.find("stage_a_kernel") != std::string::npos) emulate_stage_a(n, grid, args);
     else if (n.find("basis_kernel") != std::string::npos) emulate_basis(grid, args);
     else if (n.find("stage_b_mfma_kernel") != std::string::npos) emulate_stage_b(args);
