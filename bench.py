@@ -48,6 +48,8 @@ def parse():
                     help='storage type of the synthetic embeddings (the headline metric is float32, as the reference)')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
                     help='torch.distributed backend for the barrier / max-over-ranks (gloo: rehearsal of N > 1 on one GPU)')
+    ap.add_argument('--diag', action='store_true', help='per-rank placement / clock / power block in the line also at N = 1')
+    ap.add_argument('--diag-seconds', type=float, default=2.0, help='length of the untimed loop behind that block (N > 1)')
     ap.add_argument('--workload', choices=['c2', 'c3', 'c4', 'c5'], default='c2',
                     help='c2 = headline (fixed L, whole-sequence domains); c3 = ragged L in [50,2000]; '
                          'c4 = D=2560, L<=500, several domains per protein + whole protein; '
@@ -73,12 +75,27 @@ def make_layer(torch, gen, n_rows, D, device):
     return x
 
 
-def make_workload(args, rank, np):
-    """(lengths, domain strings per sequence or None for whole-sequence domains, D)."""
+def make_workload(args, rank, np, world: int = 1):
+    """(lengths, domain strings per sequence or None for whole-sequence domains, D) of THIS rank.
+
+    c2 is the same on every rank.  The ragged workloads are ONE job of `world` x n_seq sequences (same seed everywhere),
+    dealt to the ranks by `dist.balanced_shards` -- length-balanced, as make_db --gpu N deals a database build -- so that the
+    per-rank bytes differ by a sequence at most (independent random mixes per rank differed by the luck of the draw, and the
+    slowest rank is what the line reports)."""
     n_seq = args.n_seq
     if args.workload == 'c2':
         return np.full(n_seq, args.seq_len, dtype=np.int64), None, args.dim or 1280
-    rng = np.random.default_rng(2024 + rank)
+    lengths, doms, dim = _ragged_workload(args, np, n_seq * world)
+    if world > 1:
+        from dctdomain_amd.dist import balanced_shards
+        mine = balanced_shards(lengths.tolist(), world)[rank]
+        lengths = lengths[mine]
+        doms = None if doms is None else [doms[i] for i in mine]
+    return lengths, doms, dim
+
+
+def _ragged_workload(args, np, n_seq):
+    rng = np.random.default_rng(2024)
     if args.workload == 'c3':       # BASELINE config 3: ragged lengths, whole-sequence domains
         return rng.integers(50, 2001, size=n_seq).astype(np.int64), None, args.dim or 1280
     if args.workload == 'c5':       # BASELINE config 5 flavour: what a database build feeds the path
@@ -100,12 +117,55 @@ def make_workload(args, rank, np):
     return lengths, doms, args.dim or dim
 
 
+def sample_clock_power(step, torch, device, dev_index, seconds: float) -> dict:
+    """Loops `step` for `seconds` while a side thread asks rocm-smi for this card's shader clock and package power."""
+    import subprocess
+    import threading
+    if seconds <= 0:
+        return {}
+    stop, sclk, power = threading.Event(), [], []
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                r = subprocess.run(['rocm-smi', '-d', str(dev_index), '--showclocks', '--showpower', '--json'], capture_output=True,
+                                   text=True, timeout=5)
+                card = next(iter(json.loads(r.stdout).values()))
+                for k, v in card.items():
+                    if k.startswith('sclk clock speed'):
+                        sclk.append(float(str(v).strip('()').lower().replace('mhz', '')))
+                    elif 'Package Power' in k or 'Socket Power' in k:
+                        power.append(float(v))
+            except Exception:     # noqa: BLE001 -- diagnostics only: no rocm-smi, another json layout, a refused call
+                pass
+            stop.wait(0.4)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize(device)
+        n += 10
+    loop_ms = 1e3 * (time.perf_counter() - t0) / max(1, n)
+    stop.set()
+    th.join(timeout=6)
+    out = {'diag_loop_step_ms': round(loop_ms, 4)}
+    if len(sclk) > 1:
+        out['sclk_mhz'] = [round(sum(sclk[1:]) / len(sclk[1:])), round(min(sclk[1:]))]       # [mean, min]; first sample: ramp-up
+    if len(power) > 1:
+        out['package_power_w'] = round(sum(power[1:]) / len(power[1:]))
+    return out
+
+
 def source_sha256() -> str:
-    """sha256 over the kernel sources: what a PMC traffic measurement is valid for."""
+    """sha256 over the kernel sources (every translation unit + the two headers): what a PMC traffic measurement is valid for."""
     import hashlib
+    import build_ext
     h = hashlib.sha256()
-    for name in ('dctdomain_amd/csrc/kernels.hip.h', 'dctdomain_amd/csrc/dctfp.hip'):
-        with open(os.path.join(ROOT, name), 'rb') as fh:
+    for name in build_ext.kernel_sources():
+        with open(name, 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()
 
@@ -168,7 +228,8 @@ def main():
         ctx.set_option(k, int(v))
 
     n_seq, L = args.n_seq, args.seq_len
-    lengths, doms, D = make_workload(args, rank, np)
+    lengths, doms, D = make_workload(args, rank, np, world)
+    n_seq = len(lengths)
     total_rows = int(lengths.sum())
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
@@ -176,7 +237,9 @@ def main():
     if args.storage != 'float32':
         layers = [x.to(getattr(torch, args.storage)) for x in layers]
     offs = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+    t_tab = time.perf_counter()
     table = dd.PieceTable.whole_sequences(lengths) if doms is None else dd.PieceTable(lengths, doms)
+    piece_table_ms = 1e3 * (time.perf_counter() - t_tab)      # outside the timed loop: a caller builds it once per batch
     lbs = [dd.LayerBatch(x, 3, 80, row_offsets=offs) for x in layers]
     n_fp = table.n_domains
     out = torch.empty((n_fp, 240 * args.layers), dtype=torch.int8, device=device)
@@ -188,6 +251,14 @@ def main():
 
     for _ in range(args.warmup):
         dd.quantize_batch(lbs, table, out=out, ctx=ctx)
+    # host side of one call with the GPU idle (C-side job tables + enqueue; inside the timed loop it runs under the previous
+    # step's kernel)
+    call_host_ms = []
+    for _ in range(3):
+        torch.cuda.synchronize(device)
+        t_call = time.perf_counter()
+        dd.quantize_batch(lbs, table, out=out, ctx=ctx)
+        call_host_ms.append(1e3 * (time.perf_counter() - t_call))
     ctx.set_option('profile', 1)
     barrier()
     ctx.profile()                                   # reset the event accumulators
@@ -208,6 +279,19 @@ def main():
     slowest_kernel_ms = ddist.max_over_ranks(own_kernel_ms, device if args.backend == 'nccl' else None)
     fastest_kernel_ms = -ddist.max_over_ranks(-own_kernel_ms, device if args.backend == 'nccl' else None)
     fp_all_ranks = ddist.sum_over_ranks(n_fp, device if args.backend == 'nccl' else None)   # ragged workloads differ per rank
+
+    # ---- N > 1: what makes a bad curve readable from the line alone.  Per rank: where it ran, what it streamed, its own step
+    # and kernel time -- and clock / package power sampled while the same step loops for two more seconds (the timed region
+    # is too short for rocm-smi; the walks run a package into its power limit, eight of them share a chassis).
+    per_rank = None
+    if world > 1 or args.diag:
+        diag = dict(rank=rank, device=torch.cuda.get_device_name(device), cuda_index=dev_index, **ddist.gpu_numa(dev_index),
+                    gb_per_step=round(args.layers * total_rows * D * layers[0].element_size() / 1e9, 3),
+                    step_ms=round(1e3 * own_elapsed / args.steps, 4), kernel_launch_ms=round(own_kernel_ms, 4))
+        diag.update(sample_clock_power(lambda: dd.quantize_batch(lbs, table, out=out, ctx=ctx), torch, device, dev_index, args.diag_seconds))
+        per_rank = ddist.gather_objects(diag)
+        if world > 1:
+            dist.barrier()
 
     # ---- parity sample against the oracle (checker only; outside the timed region) ----
     parity = None
@@ -279,6 +363,10 @@ def main():
                          'whole_path_GBps': value / world * bytes_per_fp / 1e9},
             'per_rank_ms': {'step': [1e3 * fastest / args.steps, 1e3 * elapsed / args.steps],
                             'kernel_launch': [fastest_kernel_ms, slowest_kernel_ms]},      # [min, max] over the ranks
+            'per_rank': per_rank,
+            # outside the timed loop: the piece table of the batch (built once by the caller) and the host side of one call
+            'host_table_ms': {'piece_table': round(piece_table_ms, 3), 'quantize_call_idle_gpu': round(min(call_host_ms), 3),
+                              'domains': n_fp},
             'cpu_baseline': cpu_baseline,
             'parity': parity,
             'per_layer_fingerprints_per_s': value * args.layers,   # 240-byte matrix fingerprints, same GB/s

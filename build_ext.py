@@ -35,18 +35,19 @@ def _stale(target: str, sources) -> bool:
 EXPERIMENTS_LIB_PATH = os.path.join(PKG_DIR, 'libdctfp_experiments.so')
 
 
-def _library_commands(force: bool):
-    """[(target, command)] of what has to be (re)built: the product library and its twin with the engineering knobs and
-    test hooks compiled in (-DDCTFP_EXPERIMENTS: dctfp_set_option names that tools/ and the kernel-variant / cache tests use;
-    same kernels, same dispatch)."""
-    sources = [os.path.join(CSRC, 'dctfp.hip'), os.path.join(CSRC, 'kernels.hip.h'),
-               os.path.join(ROOT, 'include', 'dctfp.h')]
-    base = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-I', os.path.join(ROOT, 'include')]
-    out = []
-    for target, extra in ((LIB_PATH, []), (EXPERIMENTS_LIB_PATH, ['-DDCTFP_EXPERIMENTS'])):
-        if force or _stale(target, sources):
-            out.append((target, base + extra + ['-o', target, sources[0]]))
-    return out
+#: translation units of libdctfp.so: the host side of the C ABI, and one unit per kernel family so that the device code
+#: compiles side by side (the stage-A instantiations alone are two thirds of it).  `twin` = units that differ in
+#: libdctfp_experiments.so (-DDCTFP_EXPERIMENTS: option names, extra walk-kernel builds); the others are compiled once and
+#: linked into both libraries.
+UNITS = ['dctfp.hip', 'k_walk.hip', 'k_gen.hip', 'k_stage_b.hip', 'k_stage_a_f32.hip', 'k_stage_a_f64.hip', 'k_stage_a_half.hip']
+TWIN_UNITS = ('dctfp.hip', 'k_walk.hip')
+HEADERS = [os.path.join(CSRC, 'kernels.hip.h'), os.path.join(CSRC, 'launch.h'), os.path.join(ROOT, 'include', 'dctfp.h')]
+OBJ_DIR = os.path.join(ROOT, 'build', 'dctfp_objs')
+
+
+def kernel_sources():
+    """Every file the device code and its dispatch come from (what a PMC traffic measurement is stamped with)."""
+    return [os.path.join(CSRC, u) for u in UNITS] + HEADERS[:2]
 
 
 def sha256_of(path: str) -> str:
@@ -54,30 +55,71 @@ def sha256_of(path: str) -> str:
         return hashlib.sha256(f.read()).hexdigest()
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> dctdomain_amd/libdctfp.so (+ libdctfp_experiments.so), the two compilations side by
-    side, EACH IN ITS OWN SCRATCH DIRECTORY: hipcc leaves intermediates named after the source
-    (<src>-hip-amdgcn-amd-amdhsa.hipfb, seen on the GPU box) in its working directory, and two compilations of the same
-    dctfp.hip in one directory could hand each other's device code to the link step.  Prints the sha256 of what it built.
-    Returns the path of the product library."""
-    procs = []
-    for target, cmd in _library_commands(force):
-        if verbose:
-            print(' '.join(cmd))
-        scratch = tempfile.mkdtemp(prefix='dctfp_build_')
-        env = dict(os.environ, TMPDIR=scratch)
-        procs.append((target, cmd, scratch, subprocess.Popen(cmd, cwd=scratch, env=env)))
-    failed = None
-    for target, cmd, scratch, proc in procs:
+def _compile_flags(extra=()):
+    return [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I', os.path.join(ROOT, 'include'), '-I', CSRC] + list(extra)
+
+
+def build_library(force: bool = False, verbose: bool = False, jobs: int = None, extra_flags=(), lib_path: str = None,
+                  experiments_path: str = None) -> str:
+    """hipcc --offload-arch=gfx950: every unit -> an object (in parallel, EACH IN ITS OWN SCRATCH DIRECTORY: hipcc leaves
+    intermediates named after the source, <src>-hip-amdgcn-amd-amdhsa.hipfb seen on the GPU box, in its working directory, and
+    two compilations of the same unit there could hand each other's device code to the link step), then two links:
+    dctdomain_amd/libdctfp.so and libdctfp_experiments.so.  Prints the sha256 of what it built.  `extra_flags` / `lib_path` /
+    `experiments_path`: A/B builds with other -D switches (tools/build_variant.sh).  Returns the path of the product library."""
+    lib_path = lib_path or LIB_PATH
+    experiments_path = experiments_path or (EXPERIMENTS_LIB_PATH if lib_path == LIB_PATH else None)
+    tag = hashlib.sha256(' '.join(extra_flags).encode()).hexdigest()[:10] if extra_flags else 'default'
+    obj_dir = os.path.join(OBJ_DIR, tag)
+    os.makedirs(obj_dir, exist_ok=True)
+    todo = []   # (object, command)
+    objs = {'product': [], 'experiments': []}
+    for unit in UNITS:
+        src = os.path.join(CSRC, unit)
+        deps = [src] + HEADERS
+        variants = [('product', [])] + ([('experiments', ['-DDCTFP_EXPERIMENTS'])] if unit in TWIN_UNITS else [])
+        for kind, flags in variants:
+            obj = os.path.join(obj_dir, f'{unit[:-4]}.{kind}.o')
+            if force or _stale(obj, deps):
+                todo.append((obj, _compile_flags(list(extra_flags) + flags) + ['-c', src, '-o', obj]))
+            objs[kind].append(obj)
+        if unit not in TWIN_UNITS:
+            objs['experiments'].append(os.path.join(obj_dir, f'{unit[:-4]}.product.o'))
+    jobs = jobs or max(1, min(len(todo), (os.cpu_count() or 4)))
+    running, failed = [], None
+    queue = list(todo)
+    while queue or running:
+        while queue and len(running) < jobs:
+            obj, cmd = queue.pop(0)
+            if verbose:
+                print(' '.join(cmd))
+            scratch = tempfile.mkdtemp(prefix='dctfp_build_')
+            running.append((obj, cmd, scratch, subprocess.Popen(cmd, cwd=scratch, env=dict(os.environ, TMPDIR=scratch))))
+        obj, cmd, scratch, proc = running.pop(0)
         rc = proc.wait()
         shutil.rmtree(scratch, ignore_errors=True)
-        if rc != 0 and failed is None:
-            failed = subprocess.CalledProcessError(rc, cmd)
+        if rc != 0:
+            if os.path.exists(obj):
+                os.remove(obj)
+            failed = failed or subprocess.CalledProcessError(rc, cmd)
     if failed is not None:
         raise failed
-    for target, _, _, _ in procs:
+    built = []
+    for kind, target in (('product', lib_path), ('experiments', experiments_path)):
+        if target is None:
+            continue
+        if force or todo or _stale(target, objs[kind]):
+            cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', target] + objs[kind]
+            if verbose:
+                print(' '.join(cmd))
+            scratch = tempfile.mkdtemp(prefix='dctfp_link_')
+            try:
+                subprocess.run(cmd, check=True, cwd=scratch, env=dict(os.environ, TMPDIR=scratch))
+            finally:
+                shutil.rmtree(scratch, ignore_errors=True)
+            built.append(target)
+    for target in built:
         print(f'sha256 {sha256_of(target)}  {os.path.relpath(target, ROOT)}')
-    return LIB_PATH
+    return lib_path
 
 
 def build_all(force: bool = False, verbose: bool = False):

@@ -23,11 +23,10 @@
 #include <unordered_map>
 #include <vector>
 
-#define DCTFP_MAX_N_K DCTFP_MAX_N
-#define DCTFP_MAX_M_K DCTFP_MAX_M
-#include "kernels.hip.h"
+#include "launch.h"   // (kernels.hip.h, the parameter blocks and the launchers of the kernel families built in their own units)
 
 using namespace dctfp;
+using namespace dctfp_host;
 
 namespace {
 
@@ -53,21 +52,6 @@ int fail(int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                \
         if (e_ != hipSuccess) return fail(DCTFP_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
-
-// cos(pi p / q) in long double with exact integer argument reduction (p >= 0, q > 0).
-long double cospi_ratio_host(int64_t p, int64_t q) {
-    p %= 2 * q;
-    if (p > q) p = 2 * q - p;
-    long double sign = 1.0L;
-    if (2 * p > q) {
-        p = q - p;
-        sign = -1.0L;
-    }
-    const long double pi = 3.141592653589793238462643383279502884L;
-    long double r = (4 * p > q) ? sinl(pi * (long double)(q - 2 * p) / (long double)(2 * q))
-                                : cosl(pi * (long double)p / (long double)q);
-    return sign * r;
-}
 
 struct DevBuf {
     void* p = nullptr;
@@ -477,267 +461,33 @@ struct BasisRollback {
     }
 };
 
-template <int N>
-InvTab<N> make_inv() {
-    InvTab<N> t;
-    if constexpr (N > 1) {
-        for (int j = 0; j < N; ++j)
-            for (int k = 1; k < N; ++k)
-                t.c[j * (N - 1) + (k - 1)] = (double)cospi_ratio_host((int64_t)k * (2 * j + 1), 2 * (int64_t)N);
-    } else {
-        t.c[0] = 0.0;
+}  // namespace
+
+namespace dctfp_host {
+int launch_fail(LaunchError* err, int code, const char* fmt, ...) {
+    if (err) {
+        err->code = code;
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(err->msg, sizeof err->msg, fmt, ap);
+        va_end(ap);
     }
-    return t;
+    return code;
 }
+}  // namespace dctfp_host
 
-struct AParams {
-    const JobA* jobs;
-    const Walk* walks;
-    bool fused;
-    const PieceA* pieces;
-    unsigned long long* degenerate;
-    char* yprime;
-    int64_t job_bytes;
-    int packed;
-    int n_cols;
-    int64_t ld;
-    int ldy;
-    int n_slabs;
-    unsigned grid;
-    hipStream_t stream;
-};
+namespace {
 
-template <typename T, int N, int VEC, int WAVES, int UNROLL>
-void launch_a_impl(const AParams& p) {
-    static const InvTab<N> inv = make_inv<N>();
-    if (p.fused)
-        hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, true>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
-                           p.jobs, p.walks, p.pieces, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld, p.ldy, p.n_slabs,
-                           inv, p.degenerate);
-    else
-        hipLaunchKernelGGL((stage_a_kernel<T, N, VEC, WAVES, UNROLL, false>), dim3(p.grid), dim3(WAVES * 64), 0, p.stream,
-                           p.jobs, p.walks, p.pieces, p.yprime, p.job_bytes, p.packed, p.n_cols, p.ld, p.ldy, p.n_slabs,
-                           inv, p.degenerate);
-}
-
-template <typename T, int N, int VEC>
-void launch_a_cfg(const AParams& p, int waves, int unroll) {
-    if (waves == 1) {
-        if (unroll == 4) launch_a_impl<T, N, VEC, 1, 4>(p);
-        else launch_a_impl<T, N, VEC, 1, 8>(p);
-    } else if (waves == 2) {
-        if (unroll == 4) launch_a_impl<T, N, VEC, 2, 4>(p);
-        else launch_a_impl<T, N, VEC, 2, 8>(p);
-    } else if (waves == 8) {
-        if (unroll == 4) launch_a_impl<T, N, VEC, 8, 4>(p);
-        else launch_a_impl<T, N, VEC, 8, 8>(p);
-    } else if (waves == 16) {
-        if (unroll == 4) launch_a_impl<T, N, VEC, 16, 4>(p);
-        else launch_a_impl<T, N, VEC, 16, 8>(p);
-    } else {
-        if (unroll == 4) launch_a_impl<T, N, VEC, 4, 4>(p);
-        else launch_a_impl<T, N, VEC, 4, 8>(p);
-    }
-}
-
-template <typename T, int VEC>
-void launch_a_n(const AParams& p, int n, int waves, int unroll) {
-    switch (n) {
-        case 2: launch_a_cfg<T, 2, VEC>(p, waves, unroll); break;
-        case 3: launch_a_cfg<T, 3, VEC>(p, waves, unroll); break;
-        case 4: launch_a_impl<T, 4, VEC, 4, 4>(p); break;
-        case 5: launch_a_impl<T, 5, VEC, 4, 4>(p); break;
-        case 6: launch_a_impl<T, 6, VEC, 4, 4>(p); break;
-        case 7: launch_a_impl<T, 7, VEC, 4, 4>(p); break;
-        default: launch_a_impl<T, 8, VEC, 4, 4>(p); break;
-    }
-}
-
+// stage A of the two-kernel path, by storage type (each in its own translation unit)
 void launch_a(const AParams& p, int dtype, int vec, int n, int waves, int unroll) {
-    if (dtype == DCTFP_F32) {
-        if (vec == 4) launch_a_n<float, 4>(p, n, waves, unroll);
-        else launch_a_n<float, 1>(p, n, waves, unroll);
-    } else if (dtype == DCTFP_F16) {
-        if (vec == 8) launch_a_n<_Float16, 8>(p, n, waves, unroll);
-        else if (vec == 4) launch_a_cfg<_Float16, 3, 4>(p, waves, unroll);  // (n = 3 fused walks only)
-        else launch_a_n<_Float16, 1>(p, n, waves, unroll);
-    } else if (dtype == DCTFP_BF16) {
-        if (vec == 8) launch_a_n<bf16_t, 8>(p, n, waves, unroll);
-        else if (vec == 4) launch_a_cfg<bf16_t, 3, 4>(p, waves, unroll);
-        else launch_a_n<bf16_t, 1>(p, n, waves, unroll);
-    } else {
-        if (vec == 2) launch_a_n<double, 2>(p, n, waves, unroll);
-        else launch_a_n<double, 1>(p, n, waves, unroll);
-    }
+    if (dtype == DCTFP_F32) launch_a_f32(p, vec, n, waves, unroll);
+    else if (dtype == DCTFP_F64) launch_a_f64(p, vec, n, waves, unroll);
+    else launch_a_half(p, dtype == DCTFP_BF16, vec, n, waves, unroll);
 }
 
-void launch_b_mfma(int nt, bool packed, unsigned grid, hipStream_t s, const char* yp, int64_t job_bytes, int64_t rows,
-                   int ldy, const double* st, const JobB* jobs, int n, int m, int8_t* out) {
-#define DCTFP_B_CASE(NT)                                                                                             \
-    case NT:                                                                                                         \
-        if (packed)                                                                                                  \
-            hipLaunchKernelGGL((stage_b_mfma_kernel<NT, true>), dim3(grid), dim3(kBWaves * 64), 0, s, yp, job_bytes, rows, ldy, \
-                               st, jobs, n, m, out);                                                                 \
-        else                                                                                                         \
-            hipLaunchKernelGGL((stage_b_mfma_kernel<NT, false>), dim3(grid), dim3(kBWaves * 64), 0, s, yp, job_bytes, rows,   \
-                               ldy, st, jobs, n, m, out);                                                            \
-        break;
-    switch (nt) {
-        DCTFP_B_CASE(1)
-        DCTFP_B_CASE(2)
-        DCTFP_B_CASE(3)
-        DCTFP_B_CASE(4)
-        DCTFP_B_CASE(5)
-        DCTFP_B_CASE(6)
-        DCTFP_B_CASE(7)
-        default:
-            if (packed)
-                hipLaunchKernelGGL((stage_b_mfma_kernel<8, true>), dim3(grid), dim3(kBWaves * 64), 0, s, yp, job_bytes, rows, ldy,
-                                   st, jobs, n, m, out);
-            else
-                hipLaunchKernelGGL((stage_b_mfma_kernel<8, false>), dim3(grid), dim3(kBWaves * 64), 0, s, yp, job_bytes, rows, ldy,
-                                   st, jobs, n, m, out);
-            break;
-    }
-#undef DCTFP_B_CASE
-}
-
-struct WParams {
-    const JobA* jobs;
-    const JobB* jobb;
-    const Walk* walks;
-    const Run* runs;
-    const PieceA* pieces;
-    const double* stf;
-    int8_t* out;
-    int n_cols;
-    int64_t ld;
-    int m;
-    unsigned long long* degenerate;
-    unsigned grid;
-    hipStream_t stream;
-};
-
-template <typename T, int S, int G, int NT, int UNROLL>
-void launch_walk_impl(const WParams& p, bool fused, bool mfma_a = false) {
-    static const InvTab<3> inv = make_inv<3>();
-#ifdef DCTFP_EXPERIMENTS
-    if constexpr (sizeof(T) == 4 && UNROLL == 8 && G == 4) {
-        if (fused && mfma_a) {  // stage A on the matrix pipe (experiment of round 3: DESIGN.md section 4)
-            hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb,
-                               p.walks, p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
-            return;
-        }
-    }
-#else
-    (void)mfma_a;
-#endif
-    if (fused)
-        hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
-                           p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
-    else
-        hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, false>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
-                           p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
-}
-
-template <int S, int G>
-int launch_walk_u(const WParams& p, int unroll, bool fused, bool mfma_a) {
-#ifdef DCTFP_EXPERIMENTS
-    // rows in flight other than 8: A/B builds only (option ab_unroll, which libdctfp.so does not know)
-    if (unroll == 4) launch_walk_impl<float, S, G, 5, 4>(p, fused);
-    else if (unroll == 6) launch_walk_impl<float, S, G, 5, 6>(p, fused);
-    else if (unroll == 12 && G == 4) launch_walk_impl<float, S, 4, 5, 12>(p, fused);
-    else if (unroll == 16 && G == 4) launch_walk_impl<float, S, 4, 5, 16>(p, fused);
-    else
-#else
-    (void)unroll;
-#endif
-    launch_walk_impl<float, S, G, 5, 8>(p, fused, mfma_a);
-    return DCTFP_OK;
-}
-
-// Instantiated shapes: S waves cover up to 256 S channels; G = jobs per flush = 4, the rows of an MFMA tile (a flush costs
-// the same MFMAs for 1..4 jobs; the LDS -- 2304 B per wave and job -- leaves room for 17 waves per CU).  G = 3 and other
-// numbers of rows in flight exist in libdctfp_experiments.so only (options ab_group / ab_unroll): the product library holds
-// the 3 widths x {plain, fused} x {float32, float16, bfloat16} = 18 builds it can reach.
-int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fused, bool mfma_a) {
-    if (dtype == DCTFP_F16 || dtype == DCTFP_BF16) {
-        const bool h = dtype == DCTFP_F16;
-        if (s == 3) h ? launch_walk_impl<_Float16, 3, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 3, 4, 5, 8>(p, fused);
-        else if (s == 5) h ? launch_walk_impl<_Float16, 5, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 5, 4, 5, 8>(p, fused);
-        else h ? launch_walk_impl<_Float16, 10, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 10, 4, 5, 8>(p, fused);
-        return DCTFP_OK;
-    }
-    if (s == 3 && g == 4) return launch_walk_u<3, 4>(p, unroll, fused, mfma_a);
-    if (s == 5 && g == 4) return launch_walk_u<5, 4>(p, unroll, fused, mfma_a);
-    if (s == 10 && g == 4) return launch_walk_u<10, 4>(p, unroll, fused, mfma_a);
-#ifdef DCTFP_EXPERIMENTS
-    if (s == 3 && g == 3) return launch_walk_u<3, 3>(p, unroll, fused, mfma_a);
-    if (s == 5 && g == 3) return launch_walk_u<5, 3>(p, unroll, fused, mfma_a);
-    if (s == 10 && g == 3) return launch_walk_u<10, 3>(p, unroll, fused, mfma_a);
-#endif
-    return fail(DCTFP_ERR_INVALID, "walk kernel: no build for %d waves x %d jobs per flush", s, g);
-}
-
-// walk_gen_kernel: the shapes walk_ab_kernel does not take.
-struct GParams {
-    const JobA* jobs;
-    const JobB* jobb;
-    const Run* runs;
-    const PieceA* pieces;
-    const double* stp;
-    int8_t* out;
-    int n_cols;
-    int64_t ld;
-    int m;
-    int n_slots;
-    unsigned long long* degenerate;
-    unsigned grid;
-    unsigned waves;
-    size_t lds_bytes;
-    hipStream_t stream;
-};
-
-constexpr size_t kGenLdsBudget = 150 * 1024;  // of the 160 KB of a CU
-
-// LDS of one slot: Y'[N][CH] float64; the partial Z blocks [S][N][cp] reuse it unless a wave's columns are too few
-size_t gen_slot_bytes(int n, int m, int waves, int vec) {
-    const size_t ch = (size_t)waves * 64 * vec, cp = align_up((size_t)m, 16);
-    return ((size_t)n * ch + (cp <= (size_t)64 * vec ? 0 : (size_t)waves * n * cp)) * sizeof(double);
-}
-
-template <typename T, int N, int VEC>
-int launch_gen_impl(const GParams& p) {
-    static const InvTab<N> inv = make_inv<N>();
-    static bool attr_set = false;
-    if (!attr_set) {  // dynamic LDS above 64 KB has to be asked for, once per kernel
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&walk_gen_kernel<T, N, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(kGenLdsBudget + 1024)));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((walk_gen_kernel<T, N, VEC>), dim3(p.grid), dim3(p.waves * 64), p.lds_bytes, p.stream, p.jobs, p.jobb, p.runs,
-                       p.pieces, p.stp, p.out, p.n_cols, p.ld, p.m, p.n_slots, inv, p.degenerate);
-    return DCTFP_OK;
-}
-
-template <typename T, int VEC>
-int launch_gen_n(const GParams& p, int n) {
-    switch (n) {
-        case 2: return launch_gen_impl<T, 2, VEC>(p);
-        case 3: return launch_gen_impl<T, 3, VEC>(p);
-        case 4: return launch_gen_impl<T, 4, VEC>(p);
-        case 5: return launch_gen_impl<T, 5, VEC>(p);
-        case 6: return launch_gen_impl<T, 6, VEC>(p);
-        case 7: return launch_gen_impl<T, 7, VEC>(p);
-        case 8: return launch_gen_impl<T, 8, VEC>(p);
-        default: return fail(DCTFP_ERR_INVALID, "walk_gen_kernel: n = %d", n);
-    }
-}
-
-int launch_gen(const GParams& p, int dtype, int vec, int n) {
-    if (dtype == DCTFP_F32) return vec == 4 ? launch_gen_n<float, 4>(p, n) : launch_gen_n<float, 1>(p, n);
-    if (dtype == DCTFP_F64) return vec == 2 ? launch_gen_n<double, 2>(p, n) : launch_gen_n<double, 1>(p, n);
-    return fail(DCTFP_ERR_INVALID, "walk_gen_kernel: float32 or float64 rows");
+// a launcher's failure -> this thread's error message
+int launcher_rc(int rc, const LaunchError& err) {
+    return rc ? fail(err.code ? err.code : rc, "%s", err.msg) : DCTFP_OK;
 }
 
 int prof_begin(dctfp_ctx* ctx, int which, hipStream_t s, EventPair** ep) {
@@ -1626,7 +1376,10 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             gp.waves = (unsigned)gen_waves;
             gp.lds_bytes = (size_t)gen_slots * gen_slot_bytes(n, m, gen_waves, gen_vec) + 64;
             gp.stream = stream;
-            rc = launch_gen(gp, g.dtype, gen_vec, n);
+            {
+                LaunchError le;
+                rc = launcher_rc(launch_gen(gp, g.dtype, gen_vec, n, &le), le);
+            }
             if (rc) return rc;
             HIP_TRY(hipGetLastError());
             rc = prof_end(ep, stream);
@@ -1659,7 +1412,10 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             wp.degenerate = ctx->degenerate;
             wp.grid = (unsigned)n_runs;
             wp.stream = stream;
-            rc = launch_walk(wp, g.dtype, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : 8, fuse, ctx->opt_ab_mfma_a != 0);
+            {
+                LaunchError le;
+                rc = launcher_rc(launch_walk(wp, g.dtype, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : 8, fuse, ctx->opt_ab_mfma_a != 0, &le), le);
+            }
             if (rc) return rc;
             HIP_TRY(hipGetLastError());
             rc = prof_end(ep, stream);

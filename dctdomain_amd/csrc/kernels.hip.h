@@ -105,6 +105,7 @@ __device__ inline double sinpi_ratio(uint64_t p, uint64_t q) {
     return sign * r;
 }
 
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ void basis_kernel(const BasisJob* __restrict__ tabs, int nk) {
     const BasisJob tj = tabs[blockIdx.y];
     const uint64_t n_cos = (uint64_t)tj.len * nk;
@@ -122,6 +123,7 @@ __global__ void basis_kernel(const BasisJob* __restrict__ tabs, int nk) {
         }
     }
 }
+#endif
 
 // Raw (unconverted) register image of one row segment, so that UNROLL loads can be in
 // flight before the first conversion.  16 bytes per lane: 4 x float32, 2 x float64, 8 x float16 / bfloat16.
@@ -764,6 +766,7 @@ __global__ __launch_bounds__(kBWaves * 64, MINW) void stage_b_mfma_kernel(const 
 // K2 (VALU): same result as the MFMA kernel, one workgroup per job, plain FMAs.
 // Kept as the cross-check of the MFMA fragment layout and for A/B timing.
 // ---------------------------------------------------------------------------
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ __launch_bounds__(1024) void stage_b_valu_kernel(const double* __restrict__ yp, int ldy, int n_cols,
                                                              const double* __restrict__ st, int cp,
                                                              const JobB* __restrict__ jobs, int n, int m,
@@ -834,6 +837,7 @@ __global__ __launch_bounds__(1024) void stage_b_valu_kernel(const double* __rest
         for (int c = lane; c < m; c += 64) o[c] = quant127(bl[j * m + c] - mn, den, bad != 0);
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // K2s: stage B of a small call (a protein per call: one or two jobs).  One workgroup per job spent 46 us on the D-long
@@ -892,6 +896,7 @@ __global__ __launch_bounds__(256) void stage_b_slab_kernel(const double* __restr
     }
 }
 
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ __launch_bounds__(256) void stage_b_finish_kernel(const double* __restrict__ zpart, int n_kslabs, const JobB* __restrict__ jobs,
                                                               int n, int m, int8_t* __restrict__ out) {
     __shared__ double bl[DCTFP_MAX_N_K * DCTFP_MAX_M_K];
@@ -925,6 +930,7 @@ __global__ __launch_bounds__(256) void stage_b_finish_kernel(const double* __res
         for (int c = lane; c < m; c += 64) o[c] = quant127(bl[j * m + c] - mn, den, bad != 0);
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // K3: stage A and stage B in ONE kernel ("walk" kernel; n = 3, 64 < m <= 80; 4 channels per lane: float32 rows read as
@@ -1835,12 +1841,14 @@ __global__ __launch_bounds__(1024) void walk_gen_kernel(const JobA* __restrict__
 // Zero fill of (layer, domain) blocks whose n or m is 1: the single resampled value
 // scales to 0/0 = NaN -> 0 (golden case qdim_n1).
 // ---------------------------------------------------------------------------
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ void fill_zero_kernel(const JobB* __restrict__ jobs, int64_t n_jobs, int block_bytes,
                                  int8_t* __restrict__ out) {
     const int64_t total = n_jobs * block_bytes;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
         out[jobs[i / block_bytes].out_off + i % block_bytes] = 0;
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // Generic (any num) idct_quant pieces -- NOT a hot path; backs dctfp_idct_quant.
@@ -1866,6 +1874,7 @@ __global__ void generic_forward_kernel(const T* __restrict__ x, int64_t n_rows, 
     if (coef) coef[(size_t)c * num + k] = s * (k == 0 ? sqrt(1.0 / (double)n_rows) : sqrt(2.0 / (double)n_rows));
 }
 
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ void generic_inverse_kernel(const double* __restrict__ fs, int64_t n_cols, int num,
                                        double* __restrict__ scaled) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1887,8 +1896,10 @@ __global__ void generic_inverse_kernel(const double* __restrict__ fs, int64_t n_
         scaled[(size_t)j * n_cols + c] = bad ? __builtin_nan("") : (s - mn) / den;
     }
 }
+#endif
 
 // scale(): one workgroup, any length.
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ __launch_bounds__(256) void scale_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ out) {
     __shared__ double smn[4], smx[4];
     __shared__ int sbad[4];
@@ -1918,6 +1929,7 @@ __global__ __launch_bounds__(256) void scale_kernel(const double* __restrict__ v
     const double den = mx - mn;
     for (int64_t i = threadIdx.x; i < n; i += 256) out[i] = bad ? __builtin_nan("") : (v[i] - mn) / den;
 }
+#endif
 
 // get_doms row gather + float64 promotion; one PieceA per piece, t0 = destination row.
 template <typename T>
@@ -1957,6 +1969,7 @@ __device__ inline uint32_t topk_key(float v) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ __launch_bounds__(1024) void contact_topk_kernel(const TopkJob* __restrict__ jobs,
                                                              int32_t* __restrict__ out_i, int32_t* __restrict__ out_j,
                                                              float* __restrict__ out_v, int32_t* __restrict__ out_n) {
@@ -2044,6 +2057,7 @@ __global__ __launch_bounds__(1024) void contact_topk_kernel(const TopkJob* __res
     }
     if (threadIdx.x == 0) out_n[job.orig] = job.k;
 }
+#endif
 
 
 // ---------------------------------------------------------------------------
@@ -2120,6 +2134,7 @@ struct TopkState {  // per long protein, in global memory
     int32_t hist[256];
 };
 
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ __launch_bounds__(1024) void topk_hist_kernel(const TopkJob* __restrict__ jobs, const TopkStripe* __restrict__ stripes,
                                                           TopkState* __restrict__ state, int shift) {
     __shared__ int hist[256];
@@ -2141,7 +2156,9 @@ __global__ __launch_bounds__(1024) void topk_hist_kernel(const TopkJob* __restri
     for (int b = threadIdx.x; b < 256; b += blockDim.x)
         if (hist[b]) atomicAdd(&state[sp.job].hist[b], hist[b]);
 }
+#endif
 
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ __launch_bounds__(64) void topk_pick_kernel(const TopkJob* __restrict__ jobs, TopkState* __restrict__ state, int shift,
                                                         int32_t* __restrict__ out_n) {
     TopkState& st = state[blockIdx.x];
@@ -2158,7 +2175,9 @@ __global__ __launch_bounds__(64) void topk_pick_kernel(const TopkJob* __restrict
         for (int i = 0; i < 256; ++i) st.hist[i] = 0;
     }
 }
+#endif
 
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ __launch_bounds__(1024) void topk_collect_kernel(const TopkJob* __restrict__ jobs, const TopkStripe* __restrict__ stripes,
                                                              TopkState* __restrict__ state, int32_t* __restrict__ stripe_ties,
                                                              int32_t* __restrict__ out_i, int32_t* __restrict__ out_j,
@@ -2196,8 +2215,10 @@ __global__ __launch_bounds__(1024) void topk_collect_kernel(const TopkJob* __res
     __syncthreads();
     if (threadIdx.x == 0) stripe_ties[blockIdx.x] = s_ties;
 }
+#endif
 
 // grid = stripes; `first_stripe[job]` = index of the protein's first stripe.  Runs after topk_collect_kernel has finished.
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ __launch_bounds__(64) void topk_ties_kernel(const TopkJob* __restrict__ jobs, const TopkStripe* __restrict__ stripes,
                                                         const TopkState* __restrict__ state, const int32_t* __restrict__ stripe_ties,
                                                         const int32_t* __restrict__ first_stripe, int32_t* __restrict__ out_i,
@@ -2235,6 +2256,7 @@ __global__ __launch_bounds__(64) void topk_ties_kernel(const TopkJob* __restrict
         }
     }
 }
+#endif
 
 
 // ---------------------------------------------------------------------------
@@ -2288,6 +2310,7 @@ __global__ __launch_bounds__(256) void stitch_rows_kernel(const StitchJob* __res
 // contacts: window square n_rows x n_rows; the leading n_avg x n_avg corner overlaps the
 // running map and is averaged, everything else of the square is new (the running map is 0
 // there: new_mat = zeros, src/embedding.py:143).
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ __launch_bounds__(256) void stitch_contacts_kernel(const StitchJob* __restrict__ jobs) {
     const StitchJob job = jobs[blockIdx.y];
     const int r0 = blockIdx.x * 16;
@@ -2302,6 +2325,7 @@ __global__ __launch_bounds__(256) void stitch_contacts_kernel(const StitchJob* _
         }
     }
 }
+#endif
 
 
 // ---------------------------------------------------------------------------
@@ -2395,6 +2419,7 @@ __global__ __launch_bounds__(256) void l1_matrix_kernel(const int8_t* __restrict
 // min over every (protein_a, protein_b) block of the distance matrix + the block's last entry
 // (domain_sim, src/dct-sim.py:28-50: the max similarity over domain pairs and the similarity
 // of the two last = whole-protein fingerprints).
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ void block_min_kernel(const int32_t* __restrict__ dist, int64_t ldo, const int64_t* __restrict__ idx_a,
                                  int64_t npa, const int64_t* __restrict__ idx_b, int64_t npb,
                                  int32_t* __restrict__ out_min, int32_t* __restrict__ out_last) {
@@ -2411,6 +2436,7 @@ __global__ void block_min_kernel(const int32_t* __restrict__ dist, int64_t ldo, 
     out_min[t] = mn;
     out_last[t] = last;
 }
+#endif
 
 
 // ---------------------------------------------------------------------------
@@ -2419,6 +2445,7 @@ __global__ void block_min_kernel(const int32_t* __restrict__ dist, int64_t ldo, 
 // smallest value, collection of everything below it, and an ordered ballot walk for the ties at
 // the threshold.  Output order within a row is unspecified (the host sorts k entries).
 // ---------------------------------------------------------------------------
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ __launch_bounds__(1024) void row_select_kernel(const int32_t* __restrict__ dist, int64_t ld, int64_t n_cols,
                                                            int k, int32_t* __restrict__ out_val,
                                                            int32_t* __restrict__ out_idx) {
@@ -2488,5 +2515,6 @@ __global__ __launch_bounds__(1024) void row_select_kernel(const int32_t* __restr
         }
     }
 }
+#endif
 
 }  // namespace dctfp

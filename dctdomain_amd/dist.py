@@ -81,3 +81,58 @@ def sum_over_ranks(value: float, device: torch.device = None) -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_objects(obj) -> list:
+    """One Python object per rank on every rank (a single-process run: [obj])."""
+    if not dist.is_initialized():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def gpu_numa(device_index: int) -> dict:
+    """Where a GPU sits: PCI address, NUMA node and the node's CPU list (from sysfs; empty strings / -1 where the box does
+    not say).  No HIP call beyond torch's device properties."""
+    info = {'pci': '', 'numa_node': -1, 'cpulist': ''}
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        info['pci'] = f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0'
+        with open(f"/sys/bus/pci/devices/{info['pci']}/numa_node") as f:
+            info['numa_node'] = int(f.read().strip())
+        if info['numa_node'] >= 0:
+            with open(f"/sys/devices/system/node/node{info['numa_node']}/cpulist") as f:
+                info['cpulist'] = f.read().strip()
+    except Exception:     # noqa: BLE001 -- placement facts are optional: no GPU, no sysfs entry, another torch
+        pass
+    return info
+
+
+def _parse_cpulist(text: str) -> set:
+    cpus = set()
+    for part in text.split(','):
+        part = part.strip()
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa(device_index: int) -> dict:
+    """Keeps this process (and the threads it starts: RecCut's pool, torch's) on the CPUs of its GPU's NUMA node -- the
+    reference leaves placement to the OS (src/make_db.py:105-116); with eight workers on a two-socket host half of them
+    would otherwise stage tables and results through the far socket.  Only narrows the current affinity; a box that does
+    not report the node is left alone.  Returns what it found and did."""
+    info = gpu_numa(device_index)
+    info['pinned'] = 0
+    try:
+        allowed = os.sched_getaffinity(0)
+        want = _parse_cpulist(info['cpulist']) & allowed
+        if want and want != allowed:
+            os.sched_setaffinity(0, want)
+            info['pinned'] = len(want)
+    except (OSError, AttributeError, ValueError):
+        pass
+    return info

@@ -255,6 +255,11 @@ def _gpu_worker(rank: int, n_gpu: int, shards, model_name: str, maxlen: int, cpu
         n_dev = torch.cuda.device_count()
         dev = torch.device('cuda', rank % max(1, n_dev))
         torch.cuda.set_device(dev)
+        if n_dev > 1:           # this worker's host threads next to its GPU (one GPU: nothing to choose)
+            from .dist import pin_to_gpu_numa
+            where = pin_to_gpu_numa(dev.index)
+            logging.info(f"GPU worker {rank}: {torch.cuda.get_device_name(dev)} at {where['pci']}, NUMA node {where['numa_node']}, "
+                         f"{where['pinned'] or 'no'} CPUs pinned")
         model = load_model(model_name, dev)
         process_sequences(shards[rank], model, dev, maxlen, cpu, flush, lambda recs: out_q.put(('recs', rank, recs)))
         out_q.put(('stats', rank, dict(STAGE_SECONDS)))

@@ -60,3 +60,36 @@ def test_balanced_shards_deterministic():
     assert balanced_shards(lengths, 8) == s
     assert balanced_shards([], 4) == [[], [], [], []]
     assert balanced_shards([10, 1, 1, 1], 2) == [[0], [1, 2, 3]]
+
+
+def test_ragged_bench_workloads_are_one_job_dealt_to_the_ranks():
+    """`bench.py --workload c5 --gpus N`: the N ranks hold a length-balanced partition of ONE workload of N x n_seq sequences
+    (what make_db --gpu N does with a database), not N independent random mixes."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    argv, sys.argv = sys.argv, ['bench.py', '--workload', 'c5', '--n-seq', '500']
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    whole_l, whole_d, D = bench._ragged_workload(args, np, 1500)
+    parts = [bench.make_workload(args, r, np, 3) for r in range(3)]
+    assert sorted(np.concatenate([p[0] for p in parts]).tolist()) == sorted(whole_l.tolist())
+    assert sum(len(p[1]) for p in parts) == len(whole_d) and all(p[2] == D == 640 for p in parts)
+    rows = [int(p[0].sum()) for p in parts]
+    assert max(rows) - min(rows) <= int(whole_l.max())
+    for l, d, _ in parts:
+        assert all(dl[-1] == f'1-{L}' for L, dl in zip(l.tolist(), d))        # every sequence kept its own domain list
+    # one rank: the workload the single-GPU line has always used
+    one = bench.make_workload(args, 0, np, 1)
+    assert one[0].tolist() == bench._ragged_workload(args, np, 500)[0].tolist()
+
+
+def test_numa_helpers_do_not_need_a_gpu():
+    from dctdomain_amd import dist as dd_dist
+    assert dd_dist._parse_cpulist('0-3,8,10-11') == {0, 1, 2, 3, 8, 10, 11}
+    assert dd_dist._parse_cpulist('') == set()
+    info = dd_dist.pin_to_gpu_numa(0)            # no GPU here: nothing found, nothing changed, no exception
+    assert info['pinned'] == 0 and set(info) >= {'pci', 'numa_node', 'cpulist', 'pinned'}

@@ -50,18 +50,25 @@ def test_stub_records_match_the_kernel_header():
 def test_host_code_under_address_sanitizer(tmp_path):
     flags = ['-O1', '-g', '-std=c++17', '-fsanitize=address', '-fno-omit-frame-pointer']
     inc = ['-I', os.path.join(ROOT, 'include'), '-I', os.path.join(ROOT, 'dctdomain_amd', 'csrc')]
-    host_o, stub_o, syms, exe = (str(tmp_path / n) for n in ('dctfp_host.o', 'hip_stub.o', 'fatbin_syms.cpp', 'driver'))
-    subprocess.run([HIPCC, '--offload-arch=gfx950', '--cuda-host-only', '-fPIC', '-DDCTFP_EXPERIMENTS', *flags, *inc, '-c',
-                    os.path.join(ROOT, 'dctdomain_amd', 'csrc', 'dctfp.hip'), '-o', host_o], check=True)
+    import build_ext
+    stub_o, syms, exe = (str(tmp_path / n) for n in ('hip_stub.o', 'fatbin_syms.cpp', 'driver'))
+    inc += ['-I', os.path.join(ROOT, 'dctdomain_amd', 'csrc')]
+    host_objs, procs = [], []
+    for unit in build_ext.UNITS:          # every unit of the library, host side only (the launchers live in their own units)
+        obj = str(tmp_path / (unit[:-4] + '.host.o'))
+        host_objs.append(obj)
+        procs.append(subprocess.Popen([HIPCC, '--offload-arch=gfx950', '--cuda-host-only', '-fPIC', '-DDCTFP_EXPERIMENTS', *flags, *inc, '-c',
+                                       os.path.join(ROOT, 'dctdomain_amd', 'csrc', unit), '-o', obj]))
+    assert all(p.wait() == 0 for p in procs)
     subprocess.run([CLANG, '-D__HIP_PLATFORM_AMD__', '-fPIC', *flags, '-I', '/opt/rocm/include', '-c',
                     os.path.join(ROOT, 'tests', 'asan', 'hip_stub.cpp'), '-o', stub_o], check=True)
-    # the host object refers to the device code it would carry: an empty one will do (no kernel ever runs here)
-    undefined = subprocess.run(['nm', '-u', host_o], check=True, capture_output=True, text=True).stdout
+    # the host objects refer to the device code they would carry: empty ones will do (no kernel ever runs here)
+    undefined = subprocess.run(['nm', '-u', *host_objs], check=True, capture_output=True, text=True).stdout
     with open(syms, 'w') as fh:
         for sym in sorted(set(re.findall(r'__hip_fatbin_[0-9a-f]+', undefined))):
             fh.write(f'extern "C" {{ extern const unsigned long long {sym}[4]; const unsigned long long {sym}[4] = {{0, 0, 0, 0}}; }}\n')
     subprocess.run([CLANG, *flags, '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'asan', 'driver.cpp'), syms,
-                    host_o, stub_o, '-o', exe, '-lpthread'], check=True)
+                    *host_objs, stub_o, '-o', exe, '-lpthread'], check=True)
     env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0')
     for seed in (1, 2, 3):
         r = subprocess.run([exe, '250', str(seed)], env=env, capture_output=True, text=True, timeout=900)

@@ -1,6 +1,6 @@
 """Registers, spills, scratch and LDS of every walk-kernel variant in a device-only assembly listing:
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include [-DDCTFP_EXPERIMENTS] --cuda-device-only -S -o /tmp/dctfp.s dctdomain_amd/csrc/dctfp.hip
-    python tools/kernel_regs.py /tmp/dctfp.s [name-substring]"""
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I dctdomain_amd/csrc [-DDCTFP_EXPERIMENTS] --cuda-device-only -S -o /tmp/k_walk.s dctdomain_amd/csrc/k_walk.hip
+    python tools/kernel_regs.py /tmp/k_walk.s [name-substring]"""
 import re, sys
 text = open(sys.argv[1]).read()
 want = sys.argv[2] if len(sys.argv) > 2 else 'walk_ab_kernel'
