@@ -39,7 +39,8 @@ EXPERIMENTS_LIB_PATH = os.path.join(PKG_DIR, 'libdctfp_experiments.so')
 #: compiles side by side (the stage-A instantiations alone are two thirds of it).  `twin` = units that differ in
 #: libdctfp_experiments.so (-DDCTFP_EXPERIMENTS: option names, extra walk-kernel builds); the others are compiled once and
 #: linked into both libraries.
-UNITS = ['dctfp.hip', 'k_walk.hip', 'k_gen.hip', 'k_stage_b.hip', 'k_stage_a_f32.hip', 'k_stage_a_f64.hip', 'k_stage_a_half.hip']
+UNITS = ['dctfp.hip', 'k_walk.hip', 'k_gen.hip', 'k_stage_b.hip', 'k_stage_a_f32.hip', 'k_stage_a_f64.hip', 'k_stage_a_f16.hip',
+         'k_stage_a_bf16.hip']
 TWIN_UNITS = ('dctfp.hip', 'k_walk.hip')
 HEADERS = [os.path.join(CSRC, 'kernels.hip.h'), os.path.join(CSRC, 'launch.h'), os.path.join(ROOT, 'include', 'dctfp.h')]
 OBJ_DIR = os.path.join(ROOT, 'build', 'dctfp_objs')
@@ -60,27 +61,32 @@ def _compile_flags(extra=()):
 
 
 def build_library(force: bool = False, verbose: bool = False, jobs: int = None, extra_flags=(), lib_path: str = None,
-                  experiments_path: str = None) -> str:
+                  experiments_path: str = None, flag_units=None) -> str:
     """hipcc --offload-arch=gfx950: every unit -> an object (in parallel, EACH IN ITS OWN SCRATCH DIRECTORY: hipcc leaves
     intermediates named after the source, <src>-hip-amdgcn-amd-amdhsa.hipfb seen on the GPU box, in its working directory, and
     two compilations of the same unit there could hand each other's device code to the link step), then two links:
     dctdomain_amd/libdctfp.so and libdctfp_experiments.so.  Prints the sha256 of what it built.  `extra_flags` / `lib_path` /
     `experiments_path`: A/B builds with other -D switches (tools/build_variant.sh).  Returns the path of the product library."""
-    lib_path = lib_path or LIB_PATH
-    experiments_path = experiments_path or (EXPERIMENTS_LIB_PATH if lib_path == LIB_PATH else None)
+    lib_path = os.path.abspath(lib_path or LIB_PATH)
+    experiments_path = os.path.abspath(experiments_path) if experiments_path else (EXPERIMENTS_LIB_PATH if lib_path == LIB_PATH else None)
+    # `flag_units`: the units the extra flags are meant for (an A/B knob of the walk kernel does not touch stage A); the
+    # others are taken from the default build -- a variant costs one or two compilations instead of all seven
     tag = hashlib.sha256(' '.join(extra_flags).encode()).hexdigest()[:10] if extra_flags else 'default'
-    obj_dir = os.path.join(OBJ_DIR, tag)
-    os.makedirs(obj_dir, exist_ok=True)
     todo = []   # (object, command)
     objs = {'product': [], 'experiments': []}
     for unit in UNITS:
         src = os.path.join(CSRC, unit)
         deps = [src] + HEADERS
+        flagged = bool(extra_flags) and (flag_units is None or unit in flag_units)
+        obj_dir = os.path.join(OBJ_DIR, tag if flagged else 'default')
+        os.makedirs(obj_dir, exist_ok=True)
         variants = [('product', [])] + ([('experiments', ['-DDCTFP_EXPERIMENTS'])] if unit in TWIN_UNITS else [])
         for kind, flags in variants:
+            if kind == 'experiments' and experiments_path is None:
+                continue
             obj = os.path.join(obj_dir, f'{unit[:-4]}.{kind}.o')
             if force or _stale(obj, deps):
-                todo.append((obj, _compile_flags(list(extra_flags) + flags) + ['-c', src, '-o', obj]))
+                todo.append((obj, _compile_flags((list(extra_flags) if flagged else []) + flags) + ['-c', src, '-o', obj]))
             objs[kind].append(obj)
         if unit not in TWIN_UNITS:
             objs['experiments'].append(os.path.join(obj_dir, f'{unit[:-4]}.product.o'))

@@ -482,7 +482,8 @@ namespace {
 void launch_a(const AParams& p, int dtype, int vec, int n, int waves, int unroll) {
     if (dtype == DCTFP_F32) launch_a_f32(p, vec, n, waves, unroll);
     else if (dtype == DCTFP_F64) launch_a_f64(p, vec, n, waves, unroll);
-    else launch_a_half(p, dtype == DCTFP_BF16, vec, n, waves, unroll);
+    else if (dtype == DCTFP_F16) launch_a_f16(p, vec, n, waves, unroll);
+    else launch_a_bf16(p, vec, n, waves, unroll);
 }
 
 // a launcher's failure -> this thread's error message

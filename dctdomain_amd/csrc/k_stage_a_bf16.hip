@@ -1,4 +1,4 @@
-// stage_a_kernel, float16 / bfloat16 rows.
+// stage_a_kernel, bfloat16 rows.
 #define DCTFP_TEMPLATES_ONLY
 #include "launch.h"
 
@@ -50,16 +50,10 @@ void launch_a_n(const AParams& p, int n, int waves, int unroll) {
     }
 }
 
-void launch_a_half(const AParams& p, bool bf16, int vec, int n, int waves, int unroll) {
-    if (!bf16) {
-        if (vec == 8) launch_a_n<_Float16, 8>(p, n, waves, unroll);
-        else if (vec == 4) launch_a_cfg<_Float16, 3, 4>(p, waves, unroll);  // (n = 3 fused walks only)
-        else launch_a_n<_Float16, 1>(p, n, waves, unroll);
-    } else {
-        if (vec == 8) launch_a_n<bf16_t, 8>(p, n, waves, unroll);
-        else if (vec == 4) launch_a_cfg<bf16_t, 3, 4>(p, waves, unroll);
-        else launch_a_n<bf16_t, 1>(p, n, waves, unroll);
-    }
+void launch_a_bf16(const AParams& p, int vec, int n, int waves, int unroll) {
+    if (vec == 8) launch_a_n<bf16_t, 8>(p, n, waves, unroll);
+    else if (vec == 4) launch_a_cfg<bf16_t, 3, 4>(p, waves, unroll);  // (n = 3 fused walks only)
+    else launch_a_n<bf16_t, 1>(p, n, waves, unroll);
 }
 
 }  // namespace dctfp_host

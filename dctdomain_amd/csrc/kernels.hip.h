@@ -1042,10 +1042,10 @@ struct Run {
 
 // Instrumented build (tools/walk_timeline.py; never the shipped library): every wave adds the time (s_memrealtime: the
 // constant 100 MHz counter -- the shader clock moves with the power management, by 20 % between variants) it
-// spends per phase to degenerate[1 + phase] -- 0 stream (job record -> last row accumulated), 1 epilogue (+ the wait for the
-// slots of the last flush group, if any), 2 flush contraction (unpack + MFMA), 3 ticket, 4 wait for the last arrival + cross-wave
-// sum + int8 (the last arrivals only), 5 unused since round 4 (was: the barrier that freed the slots), 6 everything else,
-// 7 wave lifetime; 8 waves, 9 jobs, 10 flushes.
+// spends per phase to degenerate[1 + phase] -- 0 stream (job record -> last row accumulated), 1 epilogue, 2 flush contraction
+// (unpack + MFMA), 3 the last arrivals' wait for the others (round 3: every wave's wait at the barrier before the cross-wave
+// sum), 4 ticket, cross-wave sum + int8, 5 wait for the slots of the last flush group before the first write of the next (round
+// 3: the barrier that freed them), 6 everything else, 7 wave lifetime; 8 waves, 9 jobs, 10 flushes.
 #ifdef DCTFP_WALK_TIMELINE
 #define DCTFP_TL_DECL                                   \
     uint64_t tl_prev = __builtin_amdgcn_s_memrealtime();    \
@@ -1410,9 +1410,11 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 int sl = lane;
                 if constexpr (MA) asm volatile("" : "+v"(sl));
                 if (pending == 0 && done_expected != 0) {  // first write of a flush group: the rows of the last one must be out
+                    DCTFP_TL_MARK(1);
                     while (__hip_atomic_load(&lds_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != done_expected)
                         __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    DCTFP_TL_MARK(5);
                 }
                 *reinterpret_cast<v4d*>(&lds_t[wave][pending][VEC * sl]) = (v4d){tv[0], tv[1], tv[2], tv[3]};
                 lds_c[wave][pending][sl] = c4;
@@ -1577,12 +1579,12 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
                 const uint32_t idx = ticket - (uint32_t)S * flush_seq;       // my place among the arrivals of this flush
                 const uint32_t nf = pending < (uint32_t)S ? pending : (uint32_t)S;
-                DCTFP_TL_MARK(3);
                 if (idx >= (uint32_t)S - nf) {
                     const uint32_t all = (uint32_t)S * (flush_seq + 1u);
                     while (__hip_atomic_load(&lds_arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != all)
                         __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    DCTFP_TL_MARK(3);
                     for (uint32_t g = idx - ((uint32_t)S - nf); g < pending; g += nf) {
                         finish_job(g);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

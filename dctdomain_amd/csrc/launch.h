@@ -120,7 +120,8 @@ inline size_t gen_slot_bytes(int n, int m, int waves, int vec) {
 // stage A (k_stage_a_*.hip: one unit per storage type)
 void launch_a_f32(const AParams& p, int vec, int n, int waves, int unroll);
 void launch_a_f64(const AParams& p, int vec, int n, int waves, int unroll);
-void launch_a_half(const AParams& p, bool bf16, int vec, int n, int waves, int unroll);
+void launch_a_f16(const AParams& p, int vec, int n, int waves, int unroll);
+void launch_a_bf16(const AParams& p, int vec, int n, int waves, int unroll);
 // stage B on the matrix pipe (k_stage_b.hip)
 void launch_b_mfma(int nt, bool packed, unsigned grid, hipStream_t s, const char* yp, int64_t job_bytes, int64_t rows,
                    int ldy, const double* st, const JobB* jobs, int n, int m, int8_t* out);

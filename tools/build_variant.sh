@@ -4,6 +4,8 @@
 # -> build_variants/NAME.so (git-ignored; travels with gpurun).  Use with DCTFP_LIBRARY=build_variants/NAME.so.
 # Same units, same parallel build as the product (build_ext.build_library); the resource usage of every kernel goes to
 # build_variants/NAME.log (-Rpass-analysis=kernel-resource-usage), the walk kernels' lines are printed.
+# VARIANT_UNITS="k_walk.hip dctfp.hip" (default: these two and k_gen.hip): the units the flags are for; the rest comes from
+# the default build's objects.
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
@@ -12,7 +14,10 @@ python3 - "$name" "$@" <<'PY' 2> build_variants/$name.log
 import sys
 import build_ext
 name, flags = sys.argv[1], sys.argv[2:]
-build_ext.build_library(extra_flags=tuple(flags) + ('-Rpass-analysis=kernel-resource-usage',), lib_path=f'build_variants/{name}.so')
+import os
+units = os.environ.get('VARIANT_UNITS', 'k_walk.hip dctfp.hip k_gen.hip').split()
+build_ext.build_library(extra_flags=tuple(flags) + ('-Rpass-analysis=kernel-resource-usage',), lib_path=f'build_variants/{name}.so',
+                        flag_units=None if units == ['all'] else units)
 PY
 python3 - "$name" <<'PY'
 import re, sys

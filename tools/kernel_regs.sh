@@ -1,7 +1,7 @@
 #!/bin/bash
 . "$(dirname "${BASH_SOURCE[0]}")/env.sh"   # LIBC_FATAL_STDERR_, PYTHONFAULTHANDLER, DCTFP_CRASH_BACKTRACE
 # usage: tools/kernel_regs.sh [extra hipcc flags] -- VGPRs / occupancy / spills of the float32 n=3 stage-A variants and stage B
-for u in dctfp k_walk k_gen k_stage_b k_stage_a_f32 k_stage_a_f64 k_stage_a_half; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Idctdomain_amd/csrc "$@" -c dctdomain_amd/csrc/$u.hip -o /tmp/regs_$u.o -Rpass-analysis=kernel-resource-usage 2>&1; done | python3 -c "
+for u in dctfp k_walk k_gen k_stage_b k_stage_a_f32 k_stage_a_f64 k_stage_a_f16 k_stage_a_bf16; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Idctdomain_amd/csrc "$@" -c dctdomain_amd/csrc/$u.hip -o /tmp/regs_$u.o -Rpass-analysis=kernel-resource-usage 2>&1; done | python3 -c "
 import re, sys
 cur = None
 for line in sys.stdin:

@@ -14,8 +14,8 @@ import numpy as np, torch
 import dctdomain_amd as dd
 import bench
 
-PHASES = ['stream (job record -> last row)', 'epilogue (scale + pack)', 'flush: unpack + MFMA', 'wait: barrier before sum',
-          'cross-wave sum + int8', 'wait: barrier frees slots', 'other']
+PHASES = ['stream (job record -> last row)', 'epilogue (scale + pack)', 'flush: unpack + MFMA', 'wait: last arrivals for the others',
+          'ticket, cross-wave sum + int8', 'wait: slots of the last flush group', 'other']
 dev = torch.device('cuda', 0)
 ctx = dd.get_context(0)
 workloads = [a for a in sys.argv[1:] if '=' not in a] or ['c2', 'c4', 'c5']
