@@ -46,13 +46,16 @@ class PieceTable:
         n_seq = len(self.seq_rows)
         if len(domains) != n_seq:
             raise ValueError(f'{len(domains)} domain lists for {n_seq} sequences')
+        if n_seq == 1 and len(domains[0]) <= 8:   # a protein at a time: the loop over a handful of strings beats the call overhead
+            self._init_python(list(domains[0]), (len(domains[0]),))
+            return
         counts = np.fromiter(map(len, domains), dtype=np.int32, count=n_seq)
         n_str = int(counts.sum())
         try:
             text = '\n'.join(chain.from_iterable(domains)).encode('ascii')
         except (UnicodeEncodeError, TypeError):
             text = None
-        if text is None or n_str <= 8:         # (a protein at a time: the loop over a handful of strings beats the call overhead)
+        if text is None or n_str <= 8:
             self._init_python(list(chain.from_iterable(domains)), counts)
             return
         cap = len(text) // 4 + 2               # a piece is at least "b-e" and a separator
