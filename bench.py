@@ -285,10 +285,14 @@ def main():
     # is too short for rocm-smi; the walks run a package into its power limit, eight of them share a chassis).
     per_rank = None
     if world > 1 or args.diag:
-        diag = dict(rank=rank, device=torch.cuda.get_device_name(device), cuda_index=dev_index, **ddist.gpu_numa(dev_index),
-                    gb_per_step=round(args.layers * total_rows * D * layers[0].element_size() / 1e9, 3),
+        diag = dict(rank=rank, cuda_index=dev_index, gb_per_step=round(args.layers * total_rows * D * layers[0].element_size() / 1e9, 3),
                     step_ms=round(1e3 * own_elapsed / args.steps, 4), kernel_launch_ms=round(own_kernel_ms, 4))
-        diag.update(sample_clock_power(lambda: dd.quantize_batch(lbs, table, out=out, ctx=ctx), torch, device, dev_index, args.diag_seconds))
+        try:        # (diagnostics must never cost the line: whatever fails here is reported in the block, and every rank
+            #        still reaches the collective below)
+            diag.update(device=torch.cuda.get_device_name(device), **ddist.gpu_numa(dev_index))
+            diag.update(sample_clock_power(lambda: dd.quantize_batch(lbs, table, out=out, ctx=ctx), torch, device, dev_index, args.diag_seconds))
+        except Exception as exc:     # noqa: BLE001
+            diag['diag_error'] = repr(exc)[:200]
         per_rank = ddist.gather_objects(diag)
         if world > 1:
             dist.barrier()
