@@ -193,3 +193,53 @@ def test_piece_table_leaves_odd_strings_to_python():
         PieceTable([100, 50], [['1-5']])           # one domain list per sequence
     e = PieceTable([10, 10], [[], []])
     assert e.n_domains == 0 and len(e.pieces) == 0 and e.keys == []
+
+
+def test_stitch_sizes_in_c_match_the_reference_rules():
+    """dctfp_stitch_sizes (host only): rows of the stitched embedding = first window + sum(window - overlap)
+    (src/embedding.py:185-187), side of the combined contact map = inc * i + rows_i of the last window (:123-150); the
+    reference's torch expressions fail to broadcast where this returns DCTFP_ERR_SHAPE."""
+    import ctypes as C
+    from dctdomain_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+
+    def sizes(rows_per_seq, step, square):
+        rows = np.array([r for seq in rows_per_seq for r in seq], dtype=np.int32)
+        seq_win = np.zeros(len(rows_per_seq) + 1, dtype=np.int64)
+        np.cumsum([len(s) for s in rows_per_seq], out=seq_win[1:])
+        out = np.zeros(len(rows_per_seq), dtype=np.int64)
+        rc = lib.dctfp_stitch_sizes(rows.ctypes.data, seq_win.ctypes.data, len(rows_per_seq), step, square, out.ctypes.data)
+        return rc, out
+
+    for _ in range(50):
+        seqs = []
+        for _s in range(int(rng.integers(1, 9))):
+            n_win = int(rng.integers(1, 6))
+            seqs.append([500] * (n_win - 1) + [int(rng.integers(201, 501))])
+        rc, out = sizes(seqs, 200, 0)
+        assert rc == 0 and out.tolist() == [s[0] + sum(r - 200 for r in s[1:]) for s in seqs]
+        rc, out = sizes(seqs, 300, 1)
+        assert rc == 0 and out.tolist() == [300 * (len(s) - 1) + s[-1] for s in seqs]
+    assert sizes([[500, 150]], 200, 0)[0] == _lib.DCTFP_ERR_SHAPE          # a window not longer than the overlap
+    assert b'not longer than the overlap' in lib.dctfp_last_error()
+    assert sizes([[100, 500]], 200, 0)[0] == _lib.DCTFP_ERR_SHAPE          # the running embedding shorter than the overlap
+    assert sizes([[200, 300]], 300, 1)[0] == _lib.DCTFP_ERR_SHAPE          # window offset beyond the running contact map
+    assert sizes([[300, 300]], 300, 1) [0] == 0
+
+
+def test_runtime_report_and_crash_handler_exports():
+    """dctfp_runtime_info works without a GPU (the runtime answers 'no device', the maps are still read);
+    dctfp_crash_handler installs and removes itself."""
+    import ctypes as C
+    from dctdomain_amd import _lib
+    lib = _lib.load()
+    buf = C.create_string_buffer(4096)
+    n = lib.dctfp_runtime_info(buf, len(buf))
+    text = buf.value.decode()
+    assert n >= 1 and 'compiled against HIP' in text and 'libamdhip64' in text
+    assert lib.dctfp_runtime_info(buf, 8) == _lib.DCTFP_ERR_INVALID
+    assert len(_lib.mapped_runtimes()['libamdhip64']) == 1
+    assert lib.dctfp_crash_handler(1) == 0 and lib.dctfp_crash_handler(0) == 0
+    if os.environ.get('DCTFP_CRASH_BACKTRACE') == '1':
+        assert lib.dctfp_crash_handler(1) == 0      # (leave it as conftest asked for it)
