@@ -48,6 +48,8 @@ def parse():
                     help='storage type of the synthetic embeddings (the headline metric is float32, as the reference)')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
                     help='torch.distributed backend for the barrier / max-over-ranks (gloo: rehearsal of N > 1 on one GPU)')
+    ap.add_argument('--qdim', default='3,80', help='kept points n,m of every layer (default: the reference\'s 3,80; 5,44 and 3,85 are '
+                    'PROST\'s -- these run through walk_gen_kernel)')
     ap.add_argument('--diag', action='store_true', help='per-rank placement / clock / power block in the line also at N = 1')
     ap.add_argument('--diag-seconds', type=float, default=2.0, help='length of the untimed loop behind that block (N > 1)')
     ap.add_argument('--workload', choices=['c2', 'c3', 'c4', 'c5'], default='c2',
@@ -240,9 +242,10 @@ def main():
     t_tab = time.perf_counter()
     table = dd.PieceTable.whole_sequences(lengths) if doms is None else dd.PieceTable(lengths, doms)
     piece_table_ms = 1e3 * (time.perf_counter() - t_tab)      # outside the timed loop: a caller builds it once per batch
-    lbs = [dd.LayerBatch(x, 3, 80, row_offsets=offs) for x in layers]
+    qn, qm = (int(v) for v in args.qdim.split(','))
+    lbs = [dd.LayerBatch(x, qn, qm, row_offsets=offs) for x in layers]
     n_fp = table.n_domains
-    out = torch.empty((n_fp, 240 * args.layers), dtype=torch.int8, device=device)
+    out = torch.empty((n_fp, qn * qm * args.layers), dtype=torch.int8, device=device)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -311,7 +314,7 @@ def main():
             a, b = int(offs[s]), int(offs[s] + lengths[s])
             ls = [x[a:b].float().cpu().numpy() for x in layers]
             dl = [f'1-{int(lengths[s])}'] if doms is None else doms[s]
-            q = orc.quantize(ls, dl, [3, 80] * args.layers)
+            q = orc.quantize(ls, dl, [qn, qm] * args.layers)
             for k, key in enumerate(q):
                 bad += int(np.any(host[first_row[s] + k].astype(np.int64) != q[key]))
                 checked += 1
@@ -322,7 +325,7 @@ def main():
         value = total_fp / elapsed
         # algorithmic bytes: every embedding row read once per layer + the int8 output;
         # 5,120,480 B per fingerprint at C2
-        batch_bytes = args.layers * total_rows * D * layers[0].element_size() + 240 * args.layers * n_fp
+        batch_bytes = args.layers * total_rows * D * layers[0].element_size() + qn * qm * args.layers * n_fp
         bytes_per_fp = batch_bytes / n_fp
         a_launch_ms = ms_k[0] / max(1, n_k[0])
         a_bytes = batch_bytes * (args.steps / max(1, n_k[0]))               # units one stage-A launch processes
@@ -330,7 +333,9 @@ def main():
         # HBM traffic of the dominant kernel from the PMC passes (tools/profile_gpu.sh).  The file is stamped with the sha256
         # of the kernel sources it was measured on; a stamp that does not match the sources of THIS run means the number is
         # stale -> null, never a silently outdated constant.
-        kernel = 'walk_ab_kernel' if ctx.get_option('last_path') == 2 else 'stage_a_kernel'
+        # (the walk kernel of the reference's shape, the general walk kernel for every other shape of float32 / float64 rows)
+        tuned_shape = qn == 3 and 64 < qm <= 80 and 512 <= D <= 2560 and D % 4 == 0
+        kernel = ('walk_ab_kernel' if tuned_shape else 'walk_gen_kernel') if ctx.get_option('last_path') == 2 else 'stage_a_kernel'
         traffic, traffic_note = None, 'no PMC measurement for this workload / source state'
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile):
@@ -339,7 +344,7 @@ def main():
             entry = tj.get('workloads', {}).get(args.workload)
             same_shape = args.workload != 'c2' or (n_seq == 10000 and L == 500 and D == 1280)
             if entry and tj.get('source_sha256') == source_sha256() and entry.get('kernel') == kernel and same_shape \
-                    and not args.opt and args.storage == 'float32':
+                    and not args.opt and args.storage == 'float32' and args.qdim == '3,80':
                 traffic = entry['hbm_bytes_per_launch']
                 traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {tj.get('measured', '')}: 2 x FETCH_SIZE KiB + WRITE_SIZE KiB"
         line = {
@@ -349,8 +354,8 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': {
                 'c2': f'C2: {n_seq} sequences/GPU x {args.layers} layers of L={L} x D={D} {args.storage} (ESM-like '
-                      f'synthetic), one whole-sequence domain each, qdim [3,80]x{args.layers} -> '
-                      f'{240 * args.layers} int8 per fingerprint',
+                      f'synthetic), one whole-sequence domain each, qdim [{qn},{qm}]x{args.layers} -> '
+                      f'{qn * qm * args.layers} int8 per fingerprint',
                 'c3': f'C3: {n_seq} sequences/GPU, L ~ U[50,2000] ({total_rows} rows), D={D} {args.storage}, {args.layers} layers, '
                       f'whole-sequence domains, ragged batch',
                 'c4': f'C4: {n_seq} sequences/GPU, L ~ U[100,500], D={D} {args.storage}, {args.layers} layers, 1-6 domains + whole '

@@ -18,7 +18,7 @@ def find(sub, pat):
 
 def short(name):
     name = name.split('(')[0]
-    for key in ('walk_ab_kernel', 'stage_a_kernel', 'stage_b_mfma_kernel', 'stage_b_valu_kernel', 'basis_kernel'):
+    for key in ('walk_ab_kernel', 'walk_gen_kernel', 'stage_a_kernel', 'stage_b_mfma_kernel', 'stage_b_valu_kernel', 'basis_kernel'):
         if key in name:
             return key
     return name[-60:]
@@ -45,7 +45,7 @@ for f in find('trace', '*kernel_trace.csv'):
     with open(f) as fh:
         for r in csv.DictReader(fh):
             name = short(r.get('Kernel_Name', ''))
-            if name in ('walk_ab_kernel', 'stage_a_kernel'):
+            if name in ('walk_ab_kernel', 'walk_gen_kernel', 'stage_a_kernel'):
                 runs.append((int(r['Start_Timestamp']), name, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
     runs.sort()
     if runs:
@@ -90,7 +90,7 @@ if counters:
             print(f'| {k} | {c} | {len(vals)} | {m:.6g} |')
             res.setdefault(k, {})[c] = m
     print()
-    main = 'walk_ab_kernel' if 'walk_ab_kernel' in res else 'stage_a_kernel'
+    main = 'walk_ab_kernel' if 'walk_ab_kernel' in res else ('walk_gen_kernel' if 'walk_gen_kernel' in res else 'stage_a_kernel')
     if main in res and 'FETCH_SIZE' in res[main]:
         a = res[main]
         # MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
