@@ -54,6 +54,24 @@ def test_gpus2_on_one_gpu_over_gloo(launcher):
     # [min, max] over the ranks: what makes a bad scaling curve diagnosable from the line alone
     step, kern = line['per_rank_ms']['step'], line['per_rank_ms']['kernel_launch']
     assert 0 < step[0] <= step[1] == pytest.approx(line['ms_per_step']) and 0 < kern[0] <= kern[1] <= step[1]
+    # ... and per rank: where it ran, what it streamed, its own times (clock / power when rocm-smi answers)
+    ranks = line['per_rank']
+    assert [r['rank'] for r in ranks] == [0, 1] and all(r['gb_per_step'] > 0 and r['step_ms'] > 0 and 'pci' in r for r in ranks)
+    assert line['host_table_ms']['piece_table'] >= 0 and line['host_table_ms']['quantize_call_idle_gpu'] > 0
+
+
+@pytest.mark.gpu
+def test_ragged_workload_is_dealt_to_the_ranks():
+    """`--workload c5 --gpus 2`: ONE job of 2 x n_seq sequences, length-balanced over the ranks (dist.balanced_shards) -- the
+    two ranks stream the same bytes to a sequence; parity sample (multi-domain proteins, fused walks) clean."""
+    args = ['--gpus', '2', '--backend', 'gloo', '--workload', 'c5', '--n-seq', '1500', '--steps', '3', '--warmup', '1',
+            '--cpu-seconds', '0', '--parity-sample', '6', '--diag-seconds', '0.5']
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert line['n_gpus'] == 2 and line['parity']['mismatching_fingerprints'] == 0 and line['parity']['checked'] >= 6
+    gb = [r_['gb_per_step'] for r_ in line['per_rank']]
+    assert abs(gb[0] - gb[1]) <= 0.01 * max(gb), gb          # (1 330 rows x 640 channels x 4 B x 2 layers = 0.007 GB at most)
 
 
 def test_traffic_stamp_matches_the_kernel_sources():
