@@ -51,12 +51,13 @@ class PieceTable:
             return
         counts = np.fromiter(map(len, domains), dtype=np.int32, count=n_seq)
         n_str = int(counts.sum())
+        flat = list(chain.from_iterable(domains))   # the table's own list: the caller's may change before keys are asked for
         try:
-            text = '\n'.join(chain.from_iterable(domains)).encode('ascii')
+            text = '\n'.join(flat).encode('ascii')
         except (UnicodeEncodeError, TypeError):
             text = None
         if text is None or n_str <= 8:
-            self._init_python(list(chain.from_iterable(domains)), counts)
+            self._init_python(flat, counts)
             return
         cap = len(text) // 4 + 2               # a piece is at least "b-e" and a separator
         pieces = np.empty(cap, dtype=_lib.PIECE_DTYPE)
@@ -71,21 +72,20 @@ class PieceTable:
                                           changed.ctypes.data, key_text, len(key_text), C.byref(key_len), C.byref(n_dom),
                                           C.byref(n_other)), lib)
         if n_other.value:                      # a string Python's int() / split must judge (or one with a line break inside)
-            self._init_python(list(chain.from_iterable(domains)), counts)
+            self._init_python(flat, counts)
             return
         self.n_domains = n_dom.value
         self.pieces = pieces[:n_pieces.value]
         kept = str_row >= 0
         self.lengths = str_len if self.n_domains == n_str else str_len[kept]
         # keys / owner / source name the results; they are built when somebody asks (a timed loop over dctfp_quantize does not)
-        self._lazy = (domains, counts, None if self.n_domains == n_str else kept, changed,
+        self._lazy = (flat, counts, None if self.n_domains == n_str else kept, changed,
                       key_text.raw[:key_len.value] if key_len.value else b'')
 
     def _resolve(self):
-        domains, counts, kept, changed, key_blob = self._lazy
+        flat, counts, kept, changed, key_blob = self._lazy
         self._lazy = None
         n_seq, n_str = len(counts), int(counts.sum())
-        flat = list(chain.from_iterable(domains))
         owner = np.repeat(np.arange(n_seq, dtype=np.int64), counts)
         first = np.zeros(n_seq + 1, dtype=np.int64)
         np.cumsum(counts, out=first[1:])
