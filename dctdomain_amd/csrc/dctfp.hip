@@ -207,7 +207,7 @@ struct dctfp_ctx {
     int n_cu = 256;  // compute units of the device (workgroup slots of the walk kernel = n_cu x workgroups per CU)
     void *trace_dev = nullptr, *trace_host = nullptr;  // instrumented build only (walk_trace)
     int64_t trace_waves = 0;
-    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0, opt_ab_taper = 4, opt_ab_align = 2;
+    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0, opt_ab_taper = 4, opt_ab_align = 2, opt_l1_kernel = 0;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     int64_t walk_launches = 0;  // walk-kernel launches so far (a call split at a giant domain ends on the two-kernel path)
     int64_t test_fail_once = 0;                    // test hook: the next dctfp_quantize fails after its table lookups
@@ -689,6 +689,9 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) try {
     } else if (n == "ab_align") {
         if (value < 0 || value > 8) return fail(DCTFP_ERR_INVALID, "ab_align must be 0 (off) .. 8 (walks to look ahead for a run that ends on a full flush)");
         ctx->opt_ab_align = value;
+    } else if (n == "l1_kernel") {
+        if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "l1_kernel must be 0 (by alignment) or 1 (the 4-byte kernel whatever the alignment)");
+        ctx->opt_l1_kernel = value;
     } else if (n == "ab_mfma_a") {
         ctx->opt_ab_mfma_a = value ? 1 : 0;
     } else if (n == "ab_run_jobs") {
@@ -743,6 +746,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) try {
     else if (n == "ab_mfma_a") *value = ctx->opt_ab_mfma_a;
     else if (n == "ab_taper") *value = ctx->opt_ab_taper;
     else if (n == "ab_align") *value = ctx->opt_ab_align;
+    else if (n == "l1_kernel") *value = ctx->opt_l1_kernel;
     else if (n == "pack_y") *value = ctx->opt_pack_y;
     else if (n == "basis_cap_kb") *value = ctx->basis_cap_doubles / 128;
     else if (n == "basis_restarts") *value = ctx->basis_restarts;
@@ -2054,7 +2058,10 @@ int dctfp_l1_matrix(dctfp_ctx* ctx, const int8_t* a, int64_t na, int64_t lda, co
     hipStream_t stream = (hipStream_t)stream_v;
     dim3 grid((unsigned)((nb + 127) / 128), (unsigned)((na + 127) / 128));  // 128 x 128 distances per workgroup (l1_matrix_kernel)
     const bool aligned = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | (uintptr_t)lda | (uintptr_t)ldb) & 3u) == 0;
-    if (aligned) hipLaunchKernelGGL((l1_matrix_kernel<true>), grid, dim3(256), 0, stream, a, na, lda, b, nb, ldb, d, out, ldo);
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | (uintptr_t)lda | (uintptr_t)ldb) & 15u) == 0 &&
+                           lda < (1 << 24) && ldb < (1 << 24);   // (the kernel addresses a tile's rows with 32-bit offsets)
+    if (aligned16 && ctx->opt_l1_kernel != 1) hipLaunchKernelGGL(l1_matrix16_kernel, grid, dim3(256), 0, stream, a, na, lda, b, nb, ldb, d, out, ldo);
+    else if (aligned) hipLaunchKernelGGL((l1_matrix_kernel<true>), grid, dim3(256), 0, stream, a, na, lda, b, nb, ldb, d, out, ldo);
     else hipLaunchKernelGGL((l1_matrix_kernel<false>), grid, dim3(256), 0, stream, a, na, lda, b, nb, ldb, d, out, ldo);
     HIP_TRY(hipGetLastError());
     return DCTFP_OK;

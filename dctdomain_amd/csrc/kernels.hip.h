@@ -2418,6 +2418,118 @@ __global__ __launch_bounds__(256) void l1_matrix_kernel(const int8_t* __restrict
     }
 }
 
+// The same tile for rows that start on 16-byte boundaries (lda, ldb and both bases multiples of 16: every fingerprint file and
+// tensor this library produces), round 4.  tools/microbench/sad_rate.hip: v_sad_u8 from registers sustains 0.92 of its
+// 157 T/s, fed by 16 ds_read_b32 per 64 instructions (the kernel above) 0.83, by 16 ds_read_b128 per 256 0.91 -- and the
+// kernel above reached 0.59: beside the narrow LDS reads it fills its tiles with 64 four-byte global loads and as many
+// ds_write_b32 per thread and chunk, through per-byte tail code in the same loop.  Here: 16 bytes per lane from HBM / L2 to
+// LDS (8 loads + 8 ds_write_b128 per thread and chunk of 128 fingerprint bytes), row stride 36 dwords (16 lanes reading
+// 16 bytes each of 16 different rows hit 64 different banks), 4 k-steps per round of LDS reads.
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
+__global__ __launch_bounds__(256, 4) void l1_matrix16_kernel(const int8_t* __restrict__ a, int64_t na, int64_t lda,
+                                                             const int8_t* __restrict__ b, int64_t nb, int64_t ldb, int d,
+                                                             int32_t* __restrict__ out, int64_t ldo) {
+    constexpr int KC = 32, TILE = 128, LD = KC + 4;  // dwords per chunk, rows / columns per workgroup, LDS row stride
+    __shared__ uint32_t sa[TILE * LD];
+    __shared__ uint32_t sb[TILE * LD];
+    const int64_t r0 = (int64_t)blockIdx.y * TILE, c0 = (int64_t)blockIdx.x * TILE;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    uint32_t acc[8][8] = {};
+    // fill: thread -> 16-byte segment (tid & 7) of the rows tid >> 3, + 32, + 64, + 96.  Addresses = a uniform 64-bit tile base
+    // + a 32-bit lane offset (the host checks 128 * ld < 2^31): eight 64-bit row pointers held through the k loop would not fit
+    // beside the 64 accumulators.
+    const int seg = threadIdx.x & 7, frow = threadIdx.x >> 3;
+    const v4u32 flip = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};  // signed -> unsigned order, |x - y| unchanged
+    const int8_t* __restrict__ abase = a + r0 * lda;
+    const int8_t* __restrict__ bbase = b + c0 * ldb;
+    const int rows_a = (int)min((int64_t)TILE, na - r0), rows_b = (int)min((int64_t)TILE, nb - c0);
+    const uint32_t lda32 = (uint32_t)lda, ldb32 = (uint32_t)ldb;
+    // 4 k-steps: 16 bytes of 8 a rows (broadcast reads) and, two at a time, of my 8 b rows from LDS -> 256 v_sad_u8
+    auto contract = [&](int kn) {
+        for (int k = 0; k < kn; k += 4) {
+            v4u32 av[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const v4u32*>(&sa[(ty * 8 + i) * LD + k]);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {   // (64 + 32 + 8 registers)
+                v4u32 bv[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const v4u32*>(&sb[((2 * h + j) * 16 + tx) * LD + k]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][2 * h + j] = __builtin_amdgcn_sad_u8(av[i][q], bv[j][q], acc[i][2 * h + j]);
+            }
+        }
+    };
+    // the b rows sit in LDS in the order the lanes read them (column c at slot (c % 8) * 16 + c / 8: the 16 lanes of a row group
+    // read 16 consecutive slots)
+    auto b_slot = [](int r) { return (r & 7) * 16 + (r >> 3); };
+    const int d16 = d & ~15;   // whole 16-byte segments; what is left (d % 16 != 0) goes through one more, narrow round below
+    for (int byte0 = 0; byte0 < d16; byte0 += KC * 4) {
+        const int my0 = byte0 + seg * 16;   // first byte of my segment
+        const bool have = my0 < d16;        // (else past the end: both sides equal, no difference)
+        __syncthreads();
+        {
+            v4u32 va[TILE / 32], vb[TILE / 32];
+#pragma unroll
+            for (int i = 0; i < TILE / 32; ++i) {
+                const int r = frow + 32 * i;
+                va[i] = flip;
+                vb[i] = flip;
+                if (have && r < rows_a) va[i] = *reinterpret_cast<const v4u32*>(abase + ((uint32_t)r * lda32 + (uint32_t)my0));
+                if (have && r < rows_b) vb[i] = *reinterpret_cast<const v4u32*>(bbase + ((uint32_t)r * ldb32 + (uint32_t)my0));
+            }
+#pragma unroll
+            for (int i = 0; i < TILE / 32; ++i) {
+                const int r = frow + 32 * i;
+                *reinterpret_cast<v4u32*>(&sa[r * LD + seg * 4]) = va[i] ^ flip;
+                *reinterpret_cast<v4u32*>(&sb[b_slot(r) * LD + seg * 4]) = vb[i] ^ flip;
+            }
+        }
+        __syncthreads();
+        contract(min(KC, (d16 - byte0) >> 2));
+    }
+    if (d16 < d) {   // the 1..15 bytes the fingerprints end with: byte loads, one 16-byte segment per row
+        __syncthreads();
+        if (threadIdx.x < TILE) {
+            const int r = threadIdx.x;
+            v4u32 va = flip, vb = flip;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = min(4, d - d16 - 4 * q);
+                if (n > 0 && r < rows_a) va[q] = load_bytes4(abase + ((uint32_t)r * lda32 + (uint32_t)(d16 + 4 * q)), n);
+                if (n > 0 && r < rows_b) vb[q] = load_bytes4(bbase + ((uint32_t)r * ldb32 + (uint32_t)(d16 + 4 * q)), n);
+            }
+            *reinterpret_cast<v4u32*>(&sa[r * LD]) = va ^ flip;
+            *reinterpret_cast<v4u32*>(&sb[b_slot(r) * LD]) = vb ^ flip;
+        }
+        __syncthreads();
+        contract(4);
+    }
+    const int64_t c = c0 + tx * 8;
+    const bool wide = c + 8 <= nb && (ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t r = r0 + ty * 8 + i;
+        if (r >= na) continue;
+        int32_t* __restrict__ o = out + r * ldo + c;
+        if (wide) {
+            typedef int32_t v4i32 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<v4i32*>(o) = (v4i32){(int32_t)acc[i][0], (int32_t)acc[i][1], (int32_t)acc[i][2], (int32_t)acc[i][3]};
+            *reinterpret_cast<v4i32*>(o + 4) = (v4i32){(int32_t)acc[i][4], (int32_t)acc[i][5], (int32_t)acc[i][6], (int32_t)acc[i][7]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (c + j < nb) o[j] = (int32_t)acc[i][j];
+        }
+    }
+}
+
+#endif
+
 // min over every (protein_a, protein_b) block of the distance matrix + the block's last entry
 // (domain_sim, src/dct-sim.py:28-50: the max similarity over domain pairs and the similarity
 // of the two last = whole-protein fingerprints).

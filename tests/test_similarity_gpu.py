@@ -28,6 +28,42 @@ def test_l1_matrix_exact():
         np.testing.assert_array_equal(got, exp)
 
 
+def test_l1_matrix_16_byte_kernel_edges():
+    """Rows on 16-byte boundaries take l1_matrix16_kernel (round 4): widths that end inside a 16-byte segment / inside a
+    128-byte chunk (slices of wider matrices: the row stride stays a multiple of 16), row offsets, tiles past the matrix
+    edges, every byte value -- against numpy and against the 4-byte kernel (experiments library, option l1_kernel = 1)."""
+    import torch
+    from dctdomain_amd import _lib
+    from dctdomain_amd.similarity import l1_matrix
+    rng = np.random.default_rng(5)
+    wide_a = torch.from_numpy(rng.integers(-128, 128, size=(391, 528)).astype(np.int8)).cuda()
+    wide_b = torch.from_numpy(rng.integers(-128, 128, size=(300, 528)).astype(np.int8)).cuda()
+    for d in (1, 3, 15, 16, 17, 127, 128, 129, 130, 255, 470, 480, 496, 512, 528):
+        for ra, rb in ((0, 0), (1, 3)):
+            a, b = wide_a[ra:, :d], wide_b[rb:, :d]
+            assert a.data_ptr() % 16 == 0 and a.stride(0) % 16 == 0
+            exp = (a.cpu().numpy().astype(np.int64)[:, None, :] - b.cpu().numpy().astype(np.int64)[None, :, :])
+            np.testing.assert_array_equal(l1_matrix(a, b).cpu().numpy(), np.abs(exp).sum(-1), err_msg=f'd={d} rows from {ra}/{rb}')
+    # extremes: -128 against 127 in every byte, 480 wide = 255 * 480
+    lo = torch.full((130, 480), -128, dtype=torch.int8, device='cuda')
+    hi = torch.full((129, 480), 127, dtype=torch.int8, device='cuda')
+    assert (l1_matrix(lo, hi) == 255 * 480).all() and (l1_matrix(hi, hi) == 0).all()
+    # the two kernels on the same aligned input
+    ectx = _lib.experiments_context(torch.cuda.current_device())
+    a, b = wide_a[:, :480].contiguous(), wide_b[:, :480].contiguous()
+    outs = []
+    for which in (0, 1):
+        ectx.set_option('l1_kernel', which)
+        out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.int32, device='cuda')
+        _lib.check(ectx._lib.dctfp_l1_matrix(ectx.handle, a.data_ptr(), a.shape[0], 480, b.data_ptr(), b.shape[0], 480, 480,
+                                             out.data_ptr(), b.shape[0], None), ectx._lib)
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    ectx.set_option('l1_kernel', 0)
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], l1_matrix(a, b).cpu().numpy())
+
+
 def test_pair_sim_matches_G6PD_golden(tmp_path):
     from dctdomain_amd import dct_sim
     out = str(tmp_path / 'sim.txt')
