@@ -207,7 +207,7 @@ struct dctfp_ctx {
     int n_cu = 256;  // compute units of the device (workgroup slots of the walk kernel = n_cu x workgroups per CU)
     void *trace_dev = nullptr, *trace_host = nullptr;  // instrumented build only (walk_trace)
     int64_t trace_waves = 0;
-    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0, opt_ab_taper = 4, opt_ab_align = 2, opt_l1_kernel = 0;
+    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0, opt_ab_taper = 4, opt_ab_align = 2, opt_l1_kernel = 0, opt_row_select = 0;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     int64_t walk_launches = 0;  // walk-kernel launches so far (a call split at a giant domain ends on the two-kernel path)
     int64_t test_fail_once = 0;                    // test hook: the next dctfp_quantize fails after its table lookups
@@ -692,6 +692,9 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) try {
     } else if (n == "l1_kernel") {
         if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "l1_kernel must be 0 (by alignment) or 1 (the 4-byte kernel whatever the alignment)");
         ctx->opt_l1_kernel = value;
+    } else if (n == "row_select") {
+        if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "row_select must be 0 (by shape) or 1 (the radix select whatever the shape)");
+        ctx->opt_row_select = value;
     } else if (n == "ab_mfma_a") {
         ctx->opt_ab_mfma_a = value ? 1 : 0;
     } else if (n == "ab_run_jobs") {
@@ -747,6 +750,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) try {
     else if (n == "ab_taper") *value = ctx->opt_ab_taper;
     else if (n == "ab_align") *value = ctx->opt_ab_align;
     else if (n == "l1_kernel") *value = ctx->opt_l1_kernel;
+    else if (n == "row_select") *value = ctx->opt_row_select;
     else if (n == "pack_y") *value = ctx->opt_pack_y;
     else if (n == "basis_cap_kb") *value = ctx->basis_cap_doubles / 128;
     else if (n == "basis_restarts") *value = ctx->basis_restarts;
@@ -2089,8 +2093,30 @@ int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_
     if (n_rows == 0) return DCTFP_OK;
     if (n_rows > 0x7fffffff) return fail(DCTFP_ERR_LIMIT, "dctfp_row_select: too many rows");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(row_select_kernel, dim3((unsigned)n_rows), dim3(1024), 0, (hipStream_t)stream_v, dist, ld, n_cols, k,
-                       out_val, out_idx);
+    hipStream_t stream = (hipStream_t)stream_v;
+    // The row (or a segment of it) in the registers of one workgroup, read once (row_select_reg_kernel); longer rows in segments
+    // whose k candidates each a second launch selects from.  Large k, or more candidates than one workgroup holds: the radix
+    // select, which reads its row six times but has no limit.
+    constexpr int kPer = 40;
+    constexpr int64_t kSeg = 1024 * kPer;
+    const int64_t n_seg = (n_cols + kSeg - 1) / kSeg;
+    const bool reg_ok = ctx->opt_row_select != 1 && k <= 1024 && n_rows * n_seg <= 0x7fffffff && (n_seg == 1 || n_seg * k <= kSeg);
+    if (reg_ok && n_seg == 1) {
+        hipLaunchKernelGGL((row_select_reg_kernel<kPer, false>), dim3((unsigned)n_rows), dim3(1024), 0, stream, dist, (const int32_t*)nullptr,
+                           ld, n_cols, kSeg, (int64_t)1, (int)k, out_val, out_idx);
+    } else if (reg_ok) {
+        const int64_t n_in = n_seg * k;                       // candidates per row
+        int rc = ctx->scratch.ensure((size_t)n_rows * n_in * 2 * sizeof(int32_t));
+        if (rc) return rc;
+        int32_t* cand_val = (int32_t*)ctx->scratch.p;
+        int32_t* cand_idx = cand_val + (size_t)n_rows * n_in;
+        hipLaunchKernelGGL((row_select_reg_kernel<kPer, false>), dim3((unsigned)(n_rows * n_seg)), dim3(1024), 0, stream, dist,
+                           (const int32_t*)nullptr, ld, n_cols, kSeg, n_seg, (int)k, cand_val, cand_idx);
+        hipLaunchKernelGGL((row_select_reg_kernel<kPer, true>), dim3((unsigned)n_rows), dim3(1024), 0, stream, (const int32_t*)cand_val,
+                           (const int32_t*)cand_idx, n_in, n_in, n_in, (int64_t)1, (int)k, out_val, out_idx);
+    } else {
+        hipLaunchKernelGGL(row_select_kernel, dim3((unsigned)n_rows), dim3(1024), 0, stream, dist, ld, n_cols, k, out_val, out_idx);
+    }
     HIP_TRY(hipGetLastError());
     return DCTFP_OK;
 } DCTFP_GUARD("dctfp_row_select")

@@ -2631,4 +2631,204 @@ __global__ __launch_bounds__(1024) void row_select_kernel(const int32_t* __restr
 }
 #endif
 
+
+// The same selection with the row held in registers (round 4): one workgroup of 1024 threads loads up to 1024 * PER entries
+// ONCE (the radix select above reads its row six times and counts through LDS atomics that all hit a few bins: 2.6 ms for
+// 6 700 rows of 40 000 against 1.2 ms for the distance matrix itself).
+//   1. every thread keeps the minimum of its PER entries; the k-th smallest of those 1024 minima, B, is an upper bound of the
+//      k-th smallest entry T (the minima are a subset of the row) -- found by one wave, 16 minima per lane, by bisection;
+//   2. one compare per register counts the entries below B.  Fewer than k: T = B, and the entries below B plus the first
+//      ties at B (by column) are the answer.  Else the entries below B -- a few more than k -- move to LDS with their columns,
+//   3. and T is found among those by bisection on the value, 4 per thread (count = the compare's lane mask, popcount on the
+//      scalar unit, one LDS add per wave and step); where more entries equal T than are still wanted, the last column to
+//      take by bisection on the column.  More than kSelectCap entries below B (a row of few distinct values): the same
+//      bisection over the registers themselves.
+// No atomics on the data, no second read.  Rows longer than a workgroup holds go through in segments (grid = rows x
+// segments): each leaves its k candidates (value, column) in a scratch, and a second launch (COLS: columns come with the
+// values) selects among those.  A segment with fewer than k entries pads its candidates with (INT32_MAX, INT32_MAX), which
+// lose every tie.
+constexpr int kSelectCap = 4096;   // candidates the LDS holds
+struct SelectShared {
+    uint32_t cnt[96];   // one counter per counting step: no reset, one barrier per step
+    uint32_t bound, row_min, pos, fill;
+};
+__device__ inline uint32_t lane_votes(bool p) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
+
+// The kk smallest of E (key, column) pairs per thread, ties to the lowest columns: T = the kk-th smallest key by bisection
+// in [lo, hi] (n_less = count(key < lo) on entry), then emit(key, column) for each of them.  Slots without an entry hold
+// key 0xffffffff and a column > col_hi; `valid(j)` tells them from real entries of that value.
+template <int E, typename ColF, typename ValidF, typename EmitF>
+__device__ inline void bisect_emit(const uint32_t (&key)[E], ColF col_of, ValidF valid, uint32_t lo, uint32_t hi, uint32_t n_less,
+                                   uint32_t col_hi, uint32_t kk, SelectShared& sh, int& step, EmitF emit) {
+    const int lane = threadIdx.x & 63;
+    auto total = [&](uint32_t w) {   // wave counts -> sum over the workgroup; every thread gets it
+        if (lane == 0) atomicAdd(&sh.cnt[step], w);
+        __syncthreads();
+        const uint32_t t = sh.cnt[step];
+        ++step;
+        return t;
+    };
+    while (lo < hi) {   // smallest T with count(key <= T) >= kk
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        uint32_t c = 0;    // (empty slots hold 0xffffffff and mid < hi: never counted)
+#pragma unroll
+        for (int j = 0; j < E; ++j) c += lane_votes(key[j] <= mid);
+        c = total(c);
+        if (c >= kk) hi = mid;
+        else {
+            lo = mid + 1;
+            n_less = c;
+        }
+    }
+    const uint32_t thr = lo, need = kk - n_less;   // entries equal to thr still wanted (>= 1): the ones in the lowest columns
+    uint32_t ties = 0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) ties += lane_votes(valid(j) && key[j] == thr);
+    ties = total(ties);
+    uint32_t last_col = 0xffffffffu;   // take the ties up to this column
+    if (ties > need) {
+        uint32_t clo = 0, chi = col_hi;
+        while (clo < chi) {
+            const uint32_t mid = clo + ((chi - clo) >> 1);
+            uint32_t c = 0;   // (empty slots: column > col_hi > mid)
+#pragma unroll
+            for (int j = 0; j < E; ++j) c += lane_votes(key[j] == thr && col_of(j) <= mid);
+            c = total(c);
+            if (c >= need) chi = mid;
+            else clo = mid + 1;
+        }
+        last_col = clo;
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j)
+        if (valid(j) && (key[j] < thr || (key[j] == thr && col_of(j) <= last_col))) emit(key[j], col_of(j));
+}
+
+template <int PER, bool COLS>
+#ifndef DCTFP_SELECT_WAVES
+#define DCTFP_SELECT_WAVES 4   // waves per SIMD the allocation is held to: 4 = one workgroup per CU; 8 = two, with 20 of the 40 entries spilled: the same rate
+#endif
+__global__ __launch_bounds__(1024, COLS ? 4 : DCTFP_SELECT_WAVES) void row_select_reg_kernel(const int32_t* __restrict__ src_val, const int32_t* __restrict__ src_col,
+                                                                           int64_t ld, int64_t n_cols, int64_t seg_cols, int64_t n_seg, int k,
+                                                                           int32_t* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+    __shared__ SelectShared sh;
+    __shared__ uint32_t s_min[1024];
+    __shared__ uint32_t s_ckey[kSelectCap], s_ccol[kSelectCap];
+    const int64_t row = (int64_t)blockIdx.x / n_seg, seg = (int64_t)blockIdx.x % n_seg;
+    const int64_t c_first = seg * seg_cols;
+    const int n = (int)min(seg_cols, n_cols - c_first);
+    const uint32_t kk = (uint32_t)min(k, n);
+    const int32_t* __restrict__ v = src_val + row * ld + c_first;
+    const int32_t* __restrict__ cs = COLS ? src_col + row * ld + c_first : nullptr;
+    int32_t* __restrict__ ov = out_val + ((size_t)row * n_seg + seg) * k;
+    int32_t* __restrict__ oi = out_idx + ((size_t)row * n_seg + seg) * k;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 96) sh.cnt[tid] = 0;
+    if (tid == 0) {
+        sh.pos = 0;
+        sh.fill = 0;
+    }
+    // order-preserving keys, smallest first: sign bit flipped.  Element j of thread t is entry j * 1024 + t of the segment.
+    uint32_t key[PER];
+    uint32_t col[COLS ? PER : 1];
+    uint32_t kmin = 0xffffffffu;
+    {   // All loads first, unconditionally: a load under `if (c < n)` is waited for before the next one is issued -- 40 round
+        // trips to HBM per wave.  Through a buffer descriptor that ends with the segment: one lane offset for all of them
+        // (40 clamped addresses would cost 40 more registers), a slot past the end reads 0 and is overwritten below.
+        const __amdgpu_buffer_rsrc_t vb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(v), 0, n * 4, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) key[j] = __builtin_amdgcn_raw_buffer_load_b32(vb, tid * 4, j * 4096, DCTFP_STREAM_AUX);
+        if (COLS) {
+            const __amdgpu_buffer_rsrc_t cb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(cs), 0, n * 4, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) col[j] = __builtin_amdgcn_raw_buffer_load_b32(cb, tid * 4, j * 4096, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const bool have = j * 1024 + tid < n;
+            key[j] = have ? key[j] ^ 0x80000000u : 0xffffffffu;
+            if (COLS) col[j] = have ? col[j] : 0xffffffffu;
+            kmin = min(kmin, key[j]);
+        }
+    }
+    const int my_n = tid < n ? (n - tid + 1023) / 1024 : 0;  // my entries: j < my_n
+    auto col_of = [&](int j) { return COLS ? col[j] : (uint32_t)(j * 1024 + tid); };   // (segment-local, or as it came)
+    const uint32_t col_hi = COLS ? 0x7fffffffu : (uint32_t)(n - 1);
+    auto emit = [&](uint32_t key_e, uint32_t col_e) {
+        const uint32_t pos = atomicAdd(&sh.pos, 1u);
+        ov[pos] = (int32_t)(key_e ^ 0x80000000u);
+        oi[pos] = COLS ? (int32_t)col_e : (int32_t)(c_first + col_e);
+    };
+    s_min[tid] = kmin;
+    __syncthreads();
+    if (tid < 64) {   // 1.: at least kk threads hold an entry (kk <= min(n, 1024)); threads without one sort last
+        uint32_t lo = 0xffffffffu, hi = 0;   // (the minima stay in LDS: the wave's registers hold its 40 entries)
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t m = s_min[i * 64 + lane];
+            lo = min(lo, m);
+            hi = max(hi, m);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+        }
+        if (lane == 0) sh.row_min = lo;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            uint32_t c = 0;
+            for (int i = 0; i < 16; ++i) c += lane_votes(s_min[i * 64 + lane] <= mid);
+            if (c >= kk) hi = mid;
+            else lo = mid + 1;
+        }
+        if (lane == 0) sh.bound = lo;
+    }
+    __syncthreads();
+    const uint32_t bound = sh.bound, row_min = sh.row_min;
+    int step = 0;
+    uint32_t below = 0;   // 2.: (empty slots hold 0xffffffff: never below)
+#pragma unroll
+    for (int j = 0; j < PER; ++j) below += lane_votes(key[j] < bound);
+    if (lane == 0) atomicAdd(&sh.cnt[step], below);
+    __syncthreads();
+    below = sh.cnt[step];
+    ++step;
+    if (below < kk) {                          // T = bound
+        bisect_emit<PER>(key, col_of, [&](int j) { return j < my_n; }, bound, bound, below, col_hi, kk, sh, step, emit);
+    } else if (below <= (uint32_t)kSelectCap) {   // 3.: T < bound, among the `below` entries under the bound
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const bool take = key[j] < bound;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(take);
+            if (mask != 0) {   // (wave-uniform)
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&sh.fill, (uint32_t)__builtin_popcountll(mask));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (take) {
+                    s_ckey[base + rank] = key[j];
+                    s_ccol[base + rank] = col_of(j);
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int E = kSelectCap / 1024;
+        uint32_t ck[E], cc[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const uint32_t e = (uint32_t)(i * 1024 + tid);
+            ck[i] = e < below ? s_ckey[e] : 0xffffffffu;
+            cc[i] = e < below ? s_ccol[e] : 0xffffffffu;
+        }
+        bisect_emit<E>(ck, [&](int i) { return cc[i]; }, [&](int i) { return (uint32_t)(i * 1024 + tid) < below; }, row_min, bound - 1u, 0u,
+                       col_hi, kk, sh, step, emit);
+    } else {                                   // a row of few distinct values
+        bisect_emit<PER>(key, col_of, [&](int j) { return j < my_n; }, row_min, bound - 1u, 0u, col_hi, kk, sh, step, emit);
+    }
+    for (uint32_t pos = kk + (uint32_t)tid; pos < (uint32_t)k; pos += 1024) {   // a segment shorter than k: candidates that lose every tie
+        ov[pos] = 0x7fffffff;
+        oi[pos] = 0x7fffffff;
+    }
+}
+
 }  // namespace dctfp

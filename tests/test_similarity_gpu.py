@@ -124,6 +124,51 @@ def test_row_select_matches_stable_argsort():
         np.testing.assert_array_equal(v, np.take_along_axis(d, order, axis=1))
 
 
+def test_row_select_in_registers_segments_ties_and_extremes():
+    """row_select_reg_kernel (round 4: the row in the registers of one workgroup, bisection on value and column): rows of one
+    and of several segments (40 960 columns each), a last segment shorter than k, rows that are one long tie, negative and
+    extreme int32 values, k = 1 / 1024 (its limit) / 1025 (the radix select) -- against numpy's stable argsort and against
+    the radix select on the same matrix (experiments option row_select = 1), on a strided matrix."""
+    import ctypes as C
+    import torch
+    from dctdomain_amd import _lib
+    from dctdomain_amd.similarity import row_select
+    rng = np.random.default_rng(11)
+    cases = [  # rows, columns, k, values
+        (3, 40960, 100, lambda s: rng.integers(0, 120000, size=s)),
+        (2, 40965, 100, lambda s: rng.integers(0, 3, size=s)),              # second segment of 5 entries, heavy ties
+        (2, 100000, 1024, lambda s: rng.integers(-50000, 50000, size=s)),   # three segments, negative values
+        (2, 100000, 1025, lambda s: rng.integers(-50000, 50000, size=s)),   # radix select
+        (3, 90000, 7, lambda s: np.full(s, 17)),                              # one long tie: the first k columns
+        (2, 50000, 1, lambda s: rng.integers(0, 2, size=s)),
+        (2, 3000, 3000, lambda s: rng.integers(0, 10, size=s)),              # k = n_cols > 1024: radix select
+        (2, 1000, 1000, lambda s: rng.integers(0, 10, size=s)),              # k = n_cols
+        (2, 45000, 50, lambda s: rng.choice(np.array([-2**31, 2**31 - 1, 0, -1, 5]), size=s)),
+    ]
+    ectx = _lib.experiments_context(torch.cuda.current_device())
+    for n_rows, n_cols, k, gen in cases:
+        d = gen((n_rows, n_cols)).astype(np.int32)
+        wide = torch.zeros((n_rows, n_cols + 3), dtype=torch.int32, device='cuda')
+        wide[:, :n_cols] = torch.from_numpy(d).cuda()
+        dist = wide[:, :n_cols]                                              # row stride > columns
+        v, i = row_select(dist, k)
+        order = np.argsort(d, axis=1, kind='stable')[:, :k]
+        np.testing.assert_array_equal(i, order, err_msg=f'{n_rows} x {n_cols}, k = {k}')
+        np.testing.assert_array_equal(v, np.take_along_axis(d, order, axis=1))
+        outs = []
+        for which in (0, 1):
+            ectx.set_option('row_select', which)
+            val = torch.empty((n_rows, k), dtype=torch.int32, device='cuda')
+            idx = torch.empty((n_rows, k), dtype=torch.int32, device='cuda')
+            _lib.check(ectx._lib.dctfp_row_select(ectx.handle, dist.data_ptr(), n_rows, n_cols, dist.stride(0), k, val.data_ptr(),
+                                                  idx.data_ptr(), None), ectx._lib)
+            torch.cuda.synchronize()
+            vi = np.stack([val.cpu().numpy().astype(np.int64), idx.cpu().numpy().astype(np.int64)], axis=-1)
+            outs.append(np.take_along_axis(vi, np.lexsort((vi[..., 1], vi[..., 0]), axis=1)[..., None], axis=1))
+        ectx.set_option('row_select', 0)
+        np.testing.assert_array_equal(outs[0], outs[1], err_msg=f'{n_rows} x {n_cols}, k = {k}: registers vs radix select')
+
+
 def test_database_axis_tiling_and_proteins_without_fingerprints(tmp_path, monkeypatch):
     """Both consumers tile the database side as well (query_db.COL_ROWS / dct_sim.Blocks.COL_ROWS): tiny tiles must give
     the same answers as one tile; a protein with zero fingerprints in the npz (an empty stripe, data_ptr() == 0) must not
