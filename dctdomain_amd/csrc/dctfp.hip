@@ -207,7 +207,7 @@ struct dctfp_ctx {
     int n_cu = 256;  // compute units of the device (workgroup slots of the walk kernel = n_cu x workgroups per CU)
     void *trace_dev = nullptr, *trace_host = nullptr;  // instrumented build only (walk_trace)
     int64_t trace_waves = 0;
-    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0, opt_ab_taper = 4, opt_ab_align = 2, opt_l1_kernel = 0, opt_row_select = 0;
+    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0, opt_ab_taper = 4, opt_ab_align = 2, opt_l1_kernel = 0, opt_row_select = 0, opt_stitch_once = 0;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     int64_t walk_launches = 0;  // walk-kernel launches so far (a call split at a giant domain ends on the two-kernel path)
     int64_t test_fail_once = 0;                    // test hook: the next dctfp_quantize fails after its table lookups
@@ -692,6 +692,9 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) try {
     } else if (n == "l1_kernel") {
         if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "l1_kernel must be 0 (by alignment) or 1 (the 4-byte kernel whatever the alignment)");
         ctx->opt_l1_kernel = value;
+    } else if (n == "stitch_once") {
+        if (value != 0 && value != 2) return fail(DCTFP_ERR_INVALID, "stitch_once must be 0 (one launch where the windows allow it) or 2 (one launch per window index)");
+        ctx->opt_stitch_once = value;
     } else if (n == "row_select") {
         if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "row_select must be 0 (by shape) or 1 (the radix select whatever the shape)");
         ctx->opt_row_select = value;
@@ -751,6 +754,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) try {
     else if (n == "ab_align") *value = ctx->opt_ab_align;
     else if (n == "l1_kernel") *value = ctx->opt_l1_kernel;
     else if (n == "row_select") *value = ctx->opt_row_select;
+    else if (n == "stitch_once") *value = ctx->opt_stitch_once;
     else if (n == "pack_y") *value = ctx->opt_pack_y;
     else if (n == "basis_cap_kb") *value = ctx->basis_cap_doubles / 128;
     else if (n == "basis_restarts") *value = ctx->basis_restarts;
@@ -1912,7 +1916,15 @@ int dctfp_contact_sort(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
 
 namespace {
 // dctfp_stitch proper; the caller holds the context's mutex.
-int stitch_impl(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, int32_t n_cols, int32_t square, void* stream_v) {
+// `once` (embeddings only): per window the predecessor's row that meets its row 0, that window's row stride, and the rows at its
+// end that its successor writes -- all windows then go out in one launch (see StitchJob).
+struct StitchOnce {
+    const float* prev;
+    int64_t ld_prev;
+    int32_t n_skip;
+};
+int stitch_impl(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, int32_t n_cols, int32_t square, void* stream_v,
+                const StitchOnce* once = nullptr) {
     if (n_jobs < 0 || (!square && n_cols < 1)) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: bad count");
     if (n_jobs == 0) return DCTFP_OK;
     if (n_jobs > 65535 * 64) return fail(DCTFP_ERR_LIMIT, "dctfp_stitch: too many windows in one call");
@@ -1923,12 +1935,14 @@ int stitch_impl(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, in
     for (int64_t i = 0; i < n_jobs; ++i) {
         const dctfp_stitch_job& j = jobs[i];
         if (!aligned16(j.src) || !aligned16(j.dst) || (j.ld_src % 4) || (j.ld_dst % 4)) vec4 = false;
+        if (once && once[i].prev && (!aligned16(once[i].prev) || (once[i].ld_prev % 4))) vec4 = false;
         if (!j.src || !j.dst || j.n_rows < 1 || j.n_avg < 0 || j.n_avg > j.n_rows || j.level < 0 ||
             j.ld_src < (square ? j.n_rows : n_cols) || j.ld_dst < (square ? j.n_rows : n_cols))
             return fail(DCTFP_ERR_INVALID, "dctfp_stitch: window %lld is malformed", (long long)i);
         if (j.level == 0 && j.n_avg != 0) return fail(DCTFP_ERR_INVALID, "dctfp_stitch: window %lld: level 0 cannot average", (long long)i);
         max_level = std::max(max_level, j.level);
     }
+    if (once) max_level = 0;   // every window in the one launch
     const int buf = ctx->flip;
     Staging& stg = ctx->staging[buf];
     DevBuf& tab = ctx->tables[buf];
@@ -1940,20 +1954,25 @@ int stitch_impl(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, in
     // bucket the windows by level (stable), one launch per level in ascending order
     StitchJob* h = (StitchJob*)stg.p;
     std::vector<int64_t> start((size_t)max_level + 2, 0);
-    for (int64_t i = 0; i < n_jobs; ++i) start[(size_t)jobs[i].level + 1] += 1;
+    for (int64_t i = 0; i < n_jobs; ++i) start[(size_t)(once ? 0 : jobs[i].level) + 1] += 1;
     for (int32_t l = 0; l <= max_level; ++l) start[(size_t)l + 1] += start[(size_t)l];
     std::vector<int64_t> fill(start.begin(), start.end() - 1);
     std::vector<int32_t> max_rows((size_t)max_level + 1, 0);
     for (int64_t i = 0; i < n_jobs; ++i) {
         const dctfp_stitch_job& j = jobs[i];
-        StitchJob& o = h[fill[(size_t)j.level]++];
+        const int32_t level = once ? 0 : j.level;
+        StitchJob& o = h[fill[(size_t)level]++];
         o.src = (const float*)j.src;
         o.dst = (float*)j.dst;
         o.n_rows = j.n_rows;
         o.n_avg = j.n_avg;
         o.ld_src = j.ld_src;
         o.ld_dst = j.ld_dst;
-        max_rows[(size_t)j.level] = std::max(max_rows[(size_t)j.level], j.n_rows);
+        o.prev = once ? once[i].prev : nullptr;
+        o.ld_prev = once ? once[i].ld_prev : 0;
+        o.n_skip = once ? once[i].n_skip : 0;
+        o.reserved = 0;
+        max_rows[(size_t)level] = std::max(max_rows[(size_t)level], j.n_rows);
     }
     HIP_TRY(hipMemcpyAsync(tab.p, stg.p, (size_t)n_jobs * sizeof(StitchJob), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(stg.ev, stream));
@@ -2030,6 +2049,14 @@ int dctfp_stitch_sequences(dctfp_ctx* ctx, const void* const* win, const int32_t
     std::lock_guard<std::mutex> lock(ctx->mu);
     std::vector<dctfp_stitch_job> jobs;
     jobs.reserve((size_t)(n_seq > 0 ? seq_win[n_seq] - seq_win[0] : 0));
+    // Embeddings: where no window's averaged head reaches back beyond its predecessor's own rows that nobody else averaged
+    // (rows >= 2 * step for every window with a successor and a predecessor -- every shape Embedding.embed_seq produces unless
+    // maxlen < 2 * 200), the rows two windows share are averaged from the two windows and all of them go out in one launch.
+    bool simple = !square && ctx->opt_stitch_once != 2;
+    for (int64_t s = 0; s < n_seq && simple; ++s)
+        for (int64_t w = seq_win[s] + 1; w + 1 < seq_win[s + 1]; ++w)
+            if (win_rows[w] < 2 * (int64_t)step) simple = false;
+    std::vector<StitchOnce> once;
     for (int64_t s = 0; s < n_seq; ++s) {
         const int64_t w0 = seq_win[s], n = seq_win[s + 1] - w0;
         const int64_t size = stitch_geometry(win_rows + w0, n, step, square != 0, [&](int64_t w, int64_t off, int32_t n_avg) {
@@ -2043,12 +2070,19 @@ int dctfp_stitch_sequences(dctfp_ctx* ctx, const void* const* win, const int32_t
             j.level = (int32_t)w;
             j.reserved = 0;
             jobs.push_back(j);
+            if (simple) {
+                StitchOnce o;
+                o.prev = w > 0 ? (const float*)win[w0 + w - 1] + (size_t)(win_rows[w0 + w - 1] - n_avg) * (size_t)win_ld[w0 + w - 1] : nullptr;
+                o.ld_prev = w > 0 ? win_ld[w0 + w - 1] : 0;
+                o.n_skip = w + 1 < n ? step : 0;
+                once.push_back(o);
+            }
         });
         if (size < 0)
             return fail(DCTFP_ERR_SHAPE, square ? "sequence %lld: window offset beyond the running contact map"
                                                 : "sequence %lld: a window is not longer than the overlap", (long long)s);
     }
-    return stitch_impl(ctx, jobs.data(), (int64_t)jobs.size(), n_cols, square, stream_v);
+    return stitch_impl(ctx, jobs.data(), (int64_t)jobs.size(), n_cols, square, stream_v, simple ? once.data() : nullptr);
 } DCTFP_GUARD("dctfp_stitch_sequences")
 
 int dctfp_l1_matrix(dctfp_ctx* ctx, const int8_t* a, int64_t na, int64_t lda, const int8_t* b, int64_t nb, int64_t ldb,

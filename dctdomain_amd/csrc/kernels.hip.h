@@ -2275,6 +2275,14 @@ struct StitchJob {
     int32_t n_avg;     // leading rows (embedding) / leading square side (contacts) that are averaged
     int64_t ld_src;
     int64_t ld_dst;
+    // One launch for all windows (round 4, embeddings whose windows overlap their neighbours only): the rows a window shares
+    // with its predecessor are averaged from the two WINDOWS -- `prev` = the predecessor's row that meets my row 0 -- not from
+    // the running result, and the rows my successor will average (`n_skip` at my end) are left to it: every output row is
+    // written once, every window row read once, no launch waits for another.  prev == nullptr: the sequential form above.
+    const float* prev;
+    int64_t ld_prev;
+    int32_t n_skip;
+    int32_t reserved;
 };
 
 // grid.x = row blocks of 16, grid.y = job;  block = 256 threads over the columns.
@@ -2284,25 +2292,28 @@ __global__ __launch_bounds__(256) void stitch_rows_kernel(const StitchJob* __res
     const StitchJob job = jobs[blockIdx.y];
     const int r0 = blockIdx.x * 16;
     if (r0 >= job.n_rows) return;
-    const int r1 = min(job.n_rows, r0 + 16);
+    const int r1 = min(job.n_rows - job.n_skip, r0 + 16);
     for (int r = r0; r < r1; ++r) {
         const float* __restrict__ s = job.src + (size_t)r * job.ld_src;
         float* __restrict__ d = job.dst + (size_t)r * job.ld_dst;
         const bool avg = r < job.n_avg;
+        // what my row is averaged with: the running result (sequential form), or the predecessor window's own row
+        const float* __restrict__ o = job.prev ? job.prev + (size_t)r * job.ld_prev : d;
         if (VEC4) {
             const v4f* __restrict__ s4 = reinterpret_cast<const v4f*>(s);
+            const v4f* __restrict__ o4 = reinterpret_cast<const v4f*>(o);
             v4f* __restrict__ d4 = reinterpret_cast<v4f*>(d);
             for (int c = threadIdx.x; c < n_cols / 4; c += 256) {
                 const v4f a = s4[c];
                 if (avg) {
-                    const v4f b = d4[c];
+                    const v4f b = o4[c];
                     d4[c] = (v4f){(b[0] + a[0]) / 2.0f, (b[1] + a[1]) / 2.0f, (b[2] + a[2]) / 2.0f, (b[3] + a[3]) / 2.0f};
                 } else {
                     d4[c] = a;
                 }
             }
         } else if (avg) {
-            for (int c = threadIdx.x; c < n_cols; c += 256) d[c] = (d[c] + s[c]) / 2.0f;
+            for (int c = threadIdx.x; c < n_cols; c += 256) d[c] = (o[c] + s[c]) / 2.0f;
         } else {
             for (int c = threadIdx.x; c < n_cols; c += 256) d[c] = s[c];
         }

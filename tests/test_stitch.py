@@ -101,6 +101,44 @@ def test_gpu_combine_contacts_and_batch():
 
 
 @pytest.mark.gpu
+def test_gpu_batch_one_launch_and_sequential_form():
+    """Round 4: where every window overlaps its neighbours only (rows >= 2 * overlap for the windows in the middle), the
+    whole batch goes out in ONE launch that averages shared rows from the two windows; otherwise one launch per window
+    index.  Both against the reference's expression evaluated with torch (src/embedding.py:185-187), bit for bit: widths
+    that are / are not a multiple of 4, row-strided windows, a middle window of 399 rows (three windows meet: the
+    sequential form), a first window of exactly `overlap` rows, single-window sequences."""
+    from dctdomain_amd.embedding import stitch_embeddings_batch
+    g = torch.Generator(device='cuda')
+    g.manual_seed(3)
+
+    def ref(ws, step=200):
+        run = ws[0].clone()
+        for w in ws[1:]:
+            run[-step:] = (run[-step:] + w[:step]) / 2
+            run = torch.cat([run, w[step:]])
+        return run
+
+    for width, shapes in ((64, [[500, 500, 500, 300], [400, 400, 201], [500], [200, 350], [1022, 1022, 700]]),
+                          (50, [[500, 450], [401, 400, 400, 400, 250]]),
+                          (64, [[500, 399, 500], [500, 500]]),                 # 399 < 2 * 200: sequential form for the call
+                          (33, [[300, 250, 260, 201]])):                        # the same, odd width
+        batch = []
+        for rows in shapes:
+            ws = []
+            for i, r in enumerate(rows):
+                if i % 2:   # a row-strided view of a wider tensor
+                    ws.append(torch.randn((r, width + 12), device='cuda', generator=g)[:, 4:4 + width])
+                else:
+                    ws.append(torch.randn((r, width), device='cuda', generator=g))
+            batch.append(ws)
+        outs = stitch_embeddings_batch(batch)
+        for ws, o in zip(batch, outs):
+            e = ref(ws)
+            assert o.shape == e.shape
+            assert torch.equal(o, e), (width, [w.shape[0] for w in ws])
+
+
+@pytest.mark.gpu
 def test_gpu_chunked_pipeline_end_to_end():
     """BASELINE config 3 flavour: long sequence -> windows -> stitch -> reccut -> quantize, all on the
     GPU, against the oracles chained on the CPU."""
