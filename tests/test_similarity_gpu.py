@@ -169,6 +169,24 @@ def test_row_select_in_registers_segments_ties_and_extremes():
         np.testing.assert_array_equal(outs[0], outs[1], err_msg=f'{n_rows} x {n_cols}, k = {k}: registers vs radix select')
 
 
+def test_row_select_random_shapes():
+    """40 random (columns, k, value range) draws around the register kernel's limits: 1 .. 3 segments, k up to 1024, value
+    ranges from 2 (everything ties) to the whole int32 range -- against numpy's stable argsort."""
+    import torch
+    from dctdomain_amd.similarity import row_select
+    rng = np.random.default_rng(23)
+    for _ in range(40):
+        n_cols = int(rng.choice([1, 2, 63, 64, 65, 1023, 1024, 1025, 4097, 40959, 40960, 40961, 81920, 81921, int(rng.integers(1, 120000))]))
+        k = int(min(n_cols, rng.choice([1, 2, 10, 100, 1000, 1024, int(rng.integers(1, 1025))])))
+        span = int(rng.choice([2, 3, 17, 1000, 122400, 2**31 - 1]))
+        lo = int(rng.integers(-2**31, 2**31 - span))
+        d = (rng.integers(0, span, size=(2, n_cols)) + lo).astype(np.int32)
+        v, i = row_select(torch.from_numpy(d).cuda(), k)
+        order = np.argsort(d, axis=1, kind='stable')[:, :k]
+        np.testing.assert_array_equal(i, order, err_msg=f'{n_cols} columns, k = {k}, span {span}')
+        np.testing.assert_array_equal(v, np.take_along_axis(d, order, axis=1))
+
+
 def test_database_axis_tiling_and_proteins_without_fingerprints(tmp_path, monkeypatch):
     """Both consumers tile the database side as well (query_db.COL_ROWS / dct_sim.Blocks.COL_ROWS): tiny tiles must give
     the same answers as one tile; a protein with zero fingerprints in the npz (an empty stripe, data_ptr() == 0) must not
