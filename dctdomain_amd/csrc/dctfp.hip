@@ -207,7 +207,7 @@ struct dctfp_ctx {
     int n_cu = 256;  // compute units of the device (workgroup slots of the walk kernel = n_cu x workgroups per CU)
     void *trace_dev = nullptr, *trace_host = nullptr;  // instrumented build only (walk_trace)
     int64_t trace_waves = 0;
-    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0, opt_ab_taper = 4, opt_ab_align = 2, opt_l1_kernel = 0, opt_row_select = 0, opt_stitch_once = 0;
+    int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0, opt_ab_taper = 4, opt_ab_align = 2, opt_l1_kernel = 0, opt_row_select = 0, opt_stitch_once = 0, opt_topk_kernel = 0;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     int64_t walk_launches = 0;  // walk-kernel launches so far (a call split at a giant domain ends on the two-kernel path)
     int64_t test_fail_once = 0;                    // test hook: the next dctfp_quantize fails after its table lookups
@@ -695,6 +695,9 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) try {
     } else if (n == "stitch_once") {
         if (value != 0 && value != 2) return fail(DCTFP_ERR_INVALID, "stitch_once must be 0 (one launch where the windows allow it) or 2 (one launch per window index)");
         ctx->opt_stitch_once = value;
+    } else if (n == "topk_kernel") {
+        if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "topk_kernel must be 0 (two reads, radix select behind it) or 1 (radix select only)");
+        ctx->opt_topk_kernel = value;
     } else if (n == "row_select") {
         if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "row_select must be 0 (by shape) or 1 (the radix select whatever the shape)");
         ctx->opt_row_select = value;
@@ -754,6 +757,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) try {
     else if (n == "ab_align") *value = ctx->opt_ab_align;
     else if (n == "l1_kernel") *value = ctx->opt_l1_kernel;
     else if (n == "row_select") *value = ctx->opt_row_select;
+    else if (n == "topk_kernel") *value = ctx->opt_topk_kernel;
     else if (n == "stitch_once") *value = ctx->opt_stitch_once;
     else if (n == "pack_y") *value = ctx->opt_pack_y;
     else if (n == "basis_cap_kb") *value = ctx->basis_cap_doubles / 128;
@@ -1821,7 +1825,12 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
     stg.pending = true;
     const TopkJob* djobs = (const TopkJob*)tab.p;
     if (n_short > 0) {
-        hipLaunchKernelGGL(contact_topk_kernel, dim3((unsigned)n_short), dim3(1024), 0, stream, djobs, out_i, out_j, out_v, out_n);
+        if (ctx->opt_topk_kernel != 1) {   // two reads of the map; what it hands back (out_n = -1) the radix select redoes
+            hipLaunchKernelGGL(contact_topk2_kernel, dim3((unsigned)n_short), dim3(1024), 0, stream, djobs, out_i, out_j, out_v, out_n);
+            hipLaunchKernelGGL(contact_topk_kernel, dim3((unsigned)n_short), dim3(1024), 0, stream, djobs, out_i, out_j, out_v, out_n, 1);
+        } else {
+            hipLaunchKernelGGL(contact_topk_kernel, dim3((unsigned)n_short), dim3(1024), 0, stream, djobs, out_i, out_j, out_v, out_n, 0);
+        }
         HIP_TRY(hipGetLastError());
     }
     if (n_long > 0 && used_stripes > 0) {

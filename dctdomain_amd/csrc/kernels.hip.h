@@ -1974,11 +1974,12 @@ __device__ inline uint32_t topk_key(float v) {
 #ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ __launch_bounds__(1024) void contact_topk_kernel(const TopkJob* __restrict__ jobs,
                                                              int32_t* __restrict__ out_i, int32_t* __restrict__ out_j,
-                                                             float* __restrict__ out_v, int32_t* __restrict__ out_n) {
+                                                             float* __restrict__ out_v, int32_t* __restrict__ out_n, int redo_only) {
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix;
     __shared__ int s_need, s_eq, s_cnt;
     const TopkJob job = jobs[blockIdx.x];
+    if (redo_only && out_n[job.orig] != -1) return;  // (launched behind contact_topk2_kernel: only what that one handed back)
     const int L = job.n_res;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int last_row = L - 6;  // rows 0 .. L-6 have at least one j >= i + 5
@@ -2660,10 +2661,34 @@ __global__ __launch_bounds__(1024) void row_select_kernel(const int32_t* __restr
 // lose every tie.
 constexpr int kSelectCap = 4096;   // candidates the LDS holds
 struct SelectShared {
-    uint32_t cnt[96];   // one counter per counting step: no reset, one barrier per step
+    uint32_t cnt[128];  // one counter per counting step: no reset, one barrier per step
     uint32_t bound, row_min, pos, fill;
 };
 __device__ inline uint32_t lane_votes(bool p) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
+
+// The kk-th smallest of E keys per thread by bisection in [lo, hi] (which must hold it; n_less = count(key < lo) on entry,
+// = count(key < result) on return).  Slots without an entry hold 0xffffffff.
+template <int E>
+__device__ inline uint32_t kth_smallest(const uint32_t (&key)[E], uint32_t lo, uint32_t hi, uint32_t& n_less, uint32_t kk, SelectShared& sh,
+                                        int& step) {
+    const int lane = threadIdx.x & 63;
+    while (lo < hi) {   // smallest T with count(key <= T) >= kk
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        uint32_t c = 0;    // (empty slots hold 0xffffffff and mid < hi: never counted)
+#pragma unroll
+        for (int j = 0; j < E; ++j) c += lane_votes(key[j] <= mid);
+        if (lane == 0) atomicAdd(&sh.cnt[step], c);
+        __syncthreads();
+        c = sh.cnt[step];
+        ++step;
+        if (c >= kk) hi = mid;
+        else {
+            lo = mid + 1;
+            n_less = c;
+        }
+    }
+    return lo;
+}
 
 // The kk smallest of E (key, column) pairs per thread, ties to the lowest columns: T = the kk-th smallest key by bisection
 // in [lo, hi] (n_less = count(key < lo) on entry), then emit(key, column) for each of them.  Slots without an entry hold
@@ -2679,19 +2704,8 @@ __device__ inline void bisect_emit(const uint32_t (&key)[E], ColF col_of, ValidF
         ++step;
         return t;
     };
-    while (lo < hi) {   // smallest T with count(key <= T) >= kk
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        uint32_t c = 0;    // (empty slots hold 0xffffffff and mid < hi: never counted)
-#pragma unroll
-        for (int j = 0; j < E; ++j) c += lane_votes(key[j] <= mid);
-        c = total(c);
-        if (c >= kk) hi = mid;
-        else {
-            lo = mid + 1;
-            n_less = c;
-        }
-    }
-    const uint32_t thr = lo, need = kk - n_less;   // entries equal to thr still wanted (>= 1): the ones in the lowest columns
+    const uint32_t thr = kth_smallest<E>(key, lo, hi, n_less, kk, sh, step);
+    const uint32_t need = kk - n_less;   // entries equal to thr still wanted (>= 1): the ones in the lowest columns
     uint32_t ties = 0;
 #pragma unroll
     for (int j = 0; j < E; ++j) ties += lane_votes(valid(j) && key[j] == thr);
@@ -2734,7 +2748,7 @@ __global__ __launch_bounds__(1024, COLS ? 4 : DCTFP_SELECT_WAVES) void row_selec
     int32_t* __restrict__ ov = out_val + ((size_t)row * n_seg + seg) * k;
     int32_t* __restrict__ oi = out_idx + ((size_t)row * n_seg + seg) * k;
     const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < 96) sh.cnt[tid] = 0;
+    if (tid < 128) sh.cnt[tid] = 0;
     if (tid == 0) {
         sh.pos = 0;
         sh.fill = 0;
@@ -2841,5 +2855,153 @@ __global__ __launch_bounds__(1024, COLS ? 4 : DCTFP_SELECT_WAVES) void row_selec
         oi[pos] = 0x7fffffff;
     }
 }
+
+
+// ---------------------------------------------------------------------------
+// Contact top-k in two reads of the map (round 4; contact_topk_kernel above reads it six times and counts through LDS
+// atomics that mostly hit one bin).  Keys are the inverted order-preserving images of the values, so "largest value first,
+// ties in (i, j) order" is "smallest key first, ties to the lowest i << 16 | j" -- the selection of row_select_reg_kernel.
+//   1. first read: every thread keeps the M smallest keys it sees (M = 2, 4, 8 by k; a lane's position inside a 64-entry
+//      chunk rotates with the row, so that the near-diagonal band of a contact map does not land on the same few lanes);
+//      the k-th smallest of those 1024 * M keys bounds the k-th smallest key of the map from above (they are a subset);
+//   2. second read: the entries up to the bound -- a few more than k -- go to LDS with their (i, j);
+//   3. the k smallest among them, ties by (i, j): bisect_emit.  Values are read back from the map (their original bits).
+// More than kTopkCap entries up to the bound (plateaus of equal values), or k > 6144: out_n = -1, and the radix select,
+// launched behind this kernel with redo_only, does that protein.
+// ---------------------------------------------------------------------------
+constexpr int kTopkCap = 8192;
+template <int M>
+__device__ inline void topk2_run(const TopkJob& job, SelectShared& sh, uint32_t* __restrict__ s_key, uint32_t* __restrict__ s_ij,
+                                 int32_t* __restrict__ out_i, int32_t* __restrict__ out_j, float* __restrict__ out_v,
+                                 int32_t* __restrict__ out_n) {
+    const int L = job.n_res, last_row = L - 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t kk = (uint32_t)job.k;
+    auto ikey = [](float v) { return ~topk_key(v); };
+    // The candidates of a map, a wave per row pair: row i has L - 5 - i of them, so the wave takes its n-th row from the top
+    // together with its n-th from the bottom -- about (L - 5) / 64 + 1 chunks of 64 per pair whatever n is -- and requests G of
+    // them at once (one row at a time left 4 useful loads in flight at L = 500: a round trip to HBM per row and wave).
+    // f(i, j, value, valid) sees every candidate once; a lane's place inside a chunk rotates with the row.
+    // Loads go through a buffer descriptor that ends with the map (a chunk may reach past the end of its row, and of the last
+    // rows' allocation: those lanes read what follows or 0 and are not counted): row and chunk in the scalar offset, the lane's
+    // rotated place in one register per row.
+    const __amdgpu_buffer_rsrc_t mb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.map), 0, (int)((int64_t)L * job.ld * 4), 0x00020000);
+    auto stream = [&](auto f) {
+        constexpr int G = 12;
+        const int n_rows = last_row >= wave ? (last_row - wave) / 16 + 1 : 0;   // rows wave, wave + 16, ...
+        for (int n = 0; 2 * n < n_rows; ++n) {
+            const int ra = wave + 16 * n, rb = wave + 16 * (n_rows - 1 - n);
+            const int ca = (L - 5 - ra + 63) >> 6, cb = rb != ra ? (L - 5 - rb + 63) >> 6 : 0;
+            const int la = (lane + ra * 13) & 63, lb = (lane + rb * 13) & 63;
+            for (int s0 = 0; s0 < ca + cb; s0 += G) {
+                float v[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int sl = s0 + u;                                    // (everything about a slot but the lane is wave-uniform)
+                    const int i = sl < ca ? ra : rb, c = sl < ca ? sl : sl - ca;
+                    v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mb, (sl < ca ? la : lb) * 4,
+                                                                                          (int)(((int64_t)i * job.ld + i + 5 + 64 * c) * 4), 0));
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int sl = s0 + u;
+                    const int i = sl < ca ? ra : rb, c = sl < ca ? sl : sl - ca;
+                    const int j = i + 5 + 64 * c + (sl < ca ? la : lb);
+                    f(i, j, v[u], sl < ca + cb && j < L);
+                }
+            }
+        }
+    };
+    // ---- 1. my M smallest keys, ascending
+    uint32_t t[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) t[m] = 0xffffffffu;
+    stream([&](int, int, float v, bool valid) {
+        uint32_t x = valid ? ikey(v) : 0xffffffffu;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint32_t lo = min(t[m], x);
+            x = max(t[m], x);
+            t[m] = lo;
+        }
+    });
+    int step = 0;
+    uint32_t n_less = 0;
+    const uint32_t bound = kth_smallest<M>(t, 0u, 0xffffffffu, n_less, kk, sh, step);
+    // ---- 2. the entries up to the bound -> LDS
+    stream([&](int i, int j, float v, bool valid) {
+        const uint32_t x = ikey(v);
+        const bool take = valid && x <= bound;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(take);
+        if (mask != 0) {   // (wave-uniform)
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&sh.fill, (uint32_t)__builtin_popcountll(mask));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (take && at < (uint32_t)kTopkCap) {
+                s_key[at] = x;
+                s_ij[at] = ((uint32_t)i << 16) | (uint32_t)j;
+            }
+        }
+    });
+    __syncthreads();
+    const uint32_t n_cand = sh.fill;
+    if (n_cand > (uint32_t)kTopkCap) {   // plateaus: the radix select behind this kernel
+        if (tid == 0) out_n[job.orig] = -1;
+        return;
+    }
+    // ---- 3. the kk smallest of the candidates, ties to the lowest (i, j)
+    constexpr int E = kTopkCap / 1024;
+    uint32_t ck[E], cij[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t p = (uint32_t)(e * 1024 + tid);
+        ck[e] = p < n_cand ? s_key[p] : 0xffffffffu;
+        cij[e] = p < n_cand ? s_ij[p] : 0xffffffffu;
+    }
+    int32_t* __restrict__ oi = out_i + job.out_off;
+    int32_t* __restrict__ oj = out_j + job.out_off;
+    float* __restrict__ ov = out_v + job.out_off;
+    bisect_emit<E>(ck, [&](int e) { return cij[e]; }, [&](int e) { return (uint32_t)(e * 1024 + tid) < n_cand; }, 0u, bound, 0u, 0xfffffffeu, kk, sh,
+                   step, [&](uint32_t, uint32_t ij) {
+                       const uint32_t pos = atomicAdd(&sh.pos, 1u);
+                       const int i = (int)(ij >> 16), j = (int)(ij & 0xffffu);
+                       oi[pos] = i;
+                       oj[pos] = j;
+                       ov[pos] = job.map[(size_t)i * job.ld + j];
+                   });
+    if (tid == 0) out_n[job.orig] = job.k;
+}
+
+#ifndef DCTFP_TOPK_WAVES
+#define DCTFP_TOPK_WAVES 8   // waves per SIMD the allocation is held to: 8 = two workgroups per CU (nine set-up values spilled)
+#endif
+#ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
+__global__ __launch_bounds__(1024, DCTFP_TOPK_WAVES) void contact_topk2_kernel(const TopkJob* __restrict__ jobs, int32_t* __restrict__ out_i,
+                                                              int32_t* __restrict__ out_j, float* __restrict__ out_v,
+                                                              int32_t* __restrict__ out_n) {
+    __shared__ SelectShared sh;
+    __shared__ uint32_t s_key[kTopkCap], s_ij[kTopkCap];
+    const TopkJob job = jobs[blockIdx.x];
+    if (threadIdx.x < 128) sh.cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        sh.pos = 0;
+        sh.fill = 0;
+    }
+    __syncthreads();
+    if (job.k <= 0 || job.n_res < 6) {
+        if (threadIdx.x == 0) out_n[job.orig] = 0;
+        return;
+    }
+    if (job.k > 6144 || job.n_res > 65535 || (int64_t)job.n_res * job.ld >= ((int64_t)1 << 29)) {   // (more than the thread minima bound
+        // tightly / (i, j) beyond 16 bits each / a map beyond the 32-bit byte offsets of the buffer loads)
+        if (threadIdx.x == 0) out_n[job.orig] = -1;
+        return;
+    }
+    if (job.k <= 1400) topk2_run<2>(job, sh, s_key, s_ij, out_i, out_j, out_v, out_n);
+    else if (job.k <= 3000) topk2_run<4>(job, sh, s_key, s_ij, out_i, out_j, out_v, out_n);
+    else topk2_run<8>(job, sh, s_key, s_ij, out_i, out_j, out_v, out_n);
+}
+#endif
 
 }  // namespace dctfp

@@ -79,7 +79,7 @@ def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, thres
     maps = [reccut._contact_tensor(fp.contacts, n) for fp, n in zip(fps, lens)]
     ctx = _lib.get_context(maps[0].device.index)
     ctx.get_option('degenerate_seen')                          # (the flag is the context's: drop what earlier callers left unread)
-    offs, ci, cj, cv = reccut.top_contacts_batch(maps, threshold, sort=False)
+    offs, ci, cj, cv = reccut.top_contacts_batch(maps, threshold, sort=False, own=False)   # (views: used up before this call returns)
     # RecCut is host C++ (ctypes releases the GIL): it runs on its own threads while this one builds the embedding tables
     cut = {}
 

@@ -173,6 +173,36 @@ def test_gpu_topk_batch_mixed_lengths():
         np.testing.assert_array_equal(cv[a:b], ov)
 
 
+@pytest.mark.gpu
+def test_gpu_topk_two_reads_bands_ties_plateaus_and_large_k():
+    """contact_topk2_kernel (round 4: thread minima bound the k-th value, second read collects, bisection selects): maps with
+    the contacts in a band along the diagonal (what a real map looks like: the lane rotation must spread it), values
+    quantised to a few levels (ties at the threshold, more candidates than the LDS holds -> the radix select behind it),
+    one plateau, negative values and -0.0; t from 0.5 to 15 (k up to 7 500 > 6 144: handed to the radix select) -- entry
+    by entry against the oracle, in the reference's order."""
+    import torch
+    from dctdomain_amd import reccut
+    rng = np.random.default_rng(77)
+    maps = []
+    for L in (6, 30, 64, 200, 500, 777, 1400):
+        i, j = np.indices((L, L))
+        band = np.exp(-np.abs(i - j) / 6.0) * (0.6 + 0.4 * rng.random((L, L)))
+        maps.append(band.astype(np.float32))                                        # near-diagonal band
+        maps.append(rng.random((L, L)).astype(np.float32))                           # no structure, no ties
+        maps.append((np.floor(rng.random((L, L)) * 7) / 7).astype(np.float32))      # seven levels: huge tie classes
+        maps.append((rng.standard_normal((L, L)) * (rng.random((L, L)) < 0.3)).astype(np.float32) * np.float32(-1.0))  # zeros, -0.0, negatives
+    maps.append(np.full((300, 300), 0.25, dtype=np.float32))                         # one plateau
+    dev = [torch.from_numpy(m).cuda() for m in maps]
+    for t in (0.5, 2.6, 6.0, 15.0):
+        offs, ci, cj, cv = reccut.top_contacts_batch(dev, t)
+        for p, m in enumerate(maps):
+            oi, oj, ov = co.top_contacts(m, t)
+            a, b = offs[p], offs[p + 1]
+            np.testing.assert_array_equal(ci[a:b], oi, err_msg=f'map {p} (L = {m.shape[0]}), t = {t}')
+            np.testing.assert_array_equal(cj[a:b], oj, err_msg=f'map {p} (L = {m.shape[0]}), t = {t}')
+            np.testing.assert_array_equal(cv[a:b].view(np.uint32), ov.view(np.uint32), err_msg=f'map {p} (L = {m.shape[0]}), t = {t}')
+
+
 def test_contact_weight_matches_text_round_trip():
     """reccut_contact_weight == (int)(strtod("%.6f" % p) * 100 + 0.5) (src/fingerprint.py:72 + src/RecCut.cpp:384),
     checked on random probabilities and on values hugging every rounding boundary."""
