@@ -195,7 +195,10 @@ int dctfp_stitch(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, i
  * dctfp_stitch_sizes (host only, no context): rows / side of each stitched result, so that the caller can allocate;
  * DCTFP_ERR_SHAPE where the reference's torch expression would fail to broadcast (a window not longer than the overlap,
  * a window offset beyond the running map).  dctfp_stitch_sequences: dst[s] = device pointer of sequence s's result
- * (dst_ld[s] floats per row; contact maps zero-filled by the caller), then the launches of dctfp_stitch. */
+ * (dst_ld[s] floats per row; contact maps zero-filled by the caller), then the launches of dctfp_stitch -- or, for
+ * embeddings whose windows overlap their neighbours only (every window with both a predecessor and a successor has at least
+ * 2 * step rows: any maxlen >= 2 * overlap), ONE launch for all windows: the rows two windows share are averaged from the two
+ * windows, the same float32 (a + b) / 2, every row read and written once. */
 int dctfp_stitch_sizes(const int32_t* win_rows, const int64_t* seq_win, int64_t n_seq, int32_t step, int32_t square,
                        int64_t* out_rows);
 int dctfp_stitch_sequences(dctfp_ctx* ctx, const void* const* win, const int32_t* win_rows, const int64_t* win_ld,

@@ -3,6 +3,7 @@
 // runs, cosine-table list), the staging / device copies it sizes, fused-group detection, the split at giant domains, the
 // chunk plan of the two-kernel path, the option surface, the cosine-table cache (failure injection, arena restart).
 // Usage: driver [rounds] [seed]
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +60,170 @@ void operator delete[](void* p, std::align_val_t, const std::nothrow_t&) noexcep
             return 1;                                                                       \
         }                                                                                   \
     } while (0)
+
+// ---- the entry points either side of dctfp_quantize: argument checks, table builds (top-k jobs and stripes, sorting-network
+// groups, window jobs by level and in the one-launch form, candidate scratch of the row select), the host-only parsers.  The
+// kernels themselves are no-ops under the stub; what runs is every line of host code, with allocation failures injected.
+static int other_entry_points(dctfp_ctx* ctx, std::mt19937_64& rng, int rounds, int* n_calls, int* n_expected) {
+    auto uni = [&](int lo, int hi) { return (int)(lo + rng() % (uint64_t)(hi - lo + 1)); };
+    auto ok_or_expected = [&](int rc, const char* what) {
+        ++*n_calls;
+        if (rc == DCTFP_OK) return true;
+        if (rc == DCTFP_ERR_NOMEM || rc == DCTFP_ERR_SHAPE || rc == DCTFP_ERR_INVALID || rc == DCTFP_ERR_LIMIT) { ++*n_expected; return true; }
+        fprintf(stderr, "%s -> %d: %s\n", what, rc, dctfp_last_error());
+        return false;
+    };
+    for (int round = 0; round < rounds; ++round) {
+        const bool starve = uni(0, 4) == 0;
+        // ---- domain strings -> pieces (host only)
+        {
+            const int n_seq = uni(1, 40);
+            std::string text;
+            std::vector<int32_t> counts(n_seq);
+            std::vector<int64_t> rows(n_seq);
+            int64_t n_str = 0, commas = 0;
+            for (int s = 0; s < n_seq; ++s) {
+                rows[s] = uni(1, 900);
+                counts[s] = uni(0, 6);
+                for (int d = 0; d < counts[s]; ++d, ++n_str) {
+                    if (n_str) text += '\n';
+                    const int pieces = uni(1, 4);
+                    for (int q = 0; q < pieces; ++q) {
+                        if (q) { text += ','; ++commas; }
+                        const int kind = uni(0, 19);
+                        if (kind == 0) text += "x-7";                                   // not digits: left to the caller's parser
+                        else if (kind == 1) text += std::to_string(uni(0, 5)) + "-";    // nothing behind the dash
+                        else if (kind == 2) text += "0-" + std::to_string(uni(1, 50));  // the [-1:end] slice
+                        else text += std::to_string(uni(1, 1000)) + "-" + std::to_string(uni(1, 1100));
+                    }
+                }
+            }
+            const int64_t cap = n_str + commas + (uni(0, 9) == 0 ? -1 : 2);               // (sometimes too small: an error, not a write)
+            std::vector<dctfp_piece> pieces((size_t)std::max<int64_t>(cap, 1));
+            std::vector<int32_t> str_row((size_t)std::max<int64_t>(n_str, 1));
+            std::vector<int64_t> str_len((size_t)std::max<int64_t>(n_str, 1));
+            std::vector<uint8_t> changed((size_t)std::max<int64_t>(n_str, 1));
+            std::vector<char> keys(text.size() + (size_t)n_str + 1);
+            int64_t n_pieces = 0, key_len = 0, n_dom = 0, n_other = 0;
+            if (starve) g_fail_after = uni(0, 6);
+            const int rc = dctfp_build_pieces(text.data(), (int64_t)text.size(), counts.data(), rows.data(), n_seq, pieces.data(), std::max<int64_t>(cap, 0),
+                                              &n_pieces, str_row.data(), str_len.data(), changed.data(), keys.data(), (int64_t)keys.size(), &key_len,
+                                              &n_dom, &n_other);
+            g_fail_after = -1;
+            if (!ok_or_expected(rc, "dctfp_build_pieces")) return 1;
+            if (rc == DCTFP_OK && (n_pieces > std::max<int64_t>(cap, 0) || key_len > (int64_t)keys.size() || n_dom > n_str)) {
+                fprintf(stderr, "dctfp_build_pieces: counts beyond the buffers\n");
+                return 1;
+            }
+        }
+        // ---- contact top-k + order: short and long proteins (one workgroup / stripes), every t
+        {
+            const int n_prot = uni(1, 40);
+            const double t = (double[]){0.0, 0.5, 2.6, 6.0, 40.0}[uni(0, 4)];
+            std::vector<int32_t> n_res(n_prot);
+            std::vector<int64_t> ld(n_prot), offs(n_prot + 1, 0);
+            std::vector<std::vector<float>> maps(n_prot);
+            std::vector<const void*> ptrs(n_prot);
+            for (int p = 0; p < n_prot; ++p) {
+                const int c = uni(0, 19);
+                n_res[p] = c == 0 ? uni(0, 5) : (c == 1 ? uni(1500, 2100) : uni(6, 300));
+                ld[p] = n_res[p] + (uni(0, 3) == 0 ? 3 : 0);
+                maps[p].assign((size_t)std::max<int64_t>(1, (int64_t)n_res[p] * ld[p]), 0.5f);
+                ptrs[p] = maps[p].data();
+                offs[p + 1] = offs[p] + dctfp_contact_count(n_res[p], t);
+            }
+            const size_t total = (size_t)std::max<int64_t>(offs[n_prot], 1);
+            std::vector<int32_t> oi(total), oj(total), on(n_prot);
+            std::vector<float> ov(total);
+            std::vector<uint8_t> sorted(n_prot);
+            if (starve) g_fail_after = uni(0, 10);
+            int rc = dctfp_contact_topk(ctx, ptrs.data(), ld.data(), n_res.data(), n_prot, t, oi.data(), oj.data(), ov.data(), offs.data(), on.data(), nullptr);
+            g_fail_after = -1;
+            if (!ok_or_expected(rc, "dctfp_contact_topk")) return 1;
+            if (starve) g_fail_after = uni(0, 10);
+            rc = dctfp_contact_sort(ctx, ptrs.data(), ld.data(), n_res.data(), n_prot, t, oi.data(), oj.data(), ov.data(), offs.data(), sorted.data(), nullptr);
+            g_fail_after = -1;
+            if (!ok_or_expected(rc, "dctfp_contact_sort")) return 1;
+        }
+        // ---- window stitching: geometry, the one-launch form, the sequential form, malformed windows
+        {
+            const int square = uni(0, 3) == 0;
+            const int n_seq = uni(1, 30), n_cols = (int[]){32, 50, 64, 1280}[uni(0, 3)];
+            const int step = square ? uni(20, 60) : (int[]){200, 50, 7}[uni(0, 2)];
+            std::vector<int64_t> seq_win(n_seq + 1, 0), win_ld;
+            std::vector<int32_t> win_rows;
+            for (int s = 0; s < n_seq; ++s) {
+                const int n = uni(1, 6);
+                for (int w = 0; w < n; ++w) {
+                    const int c = uni(0, 29);
+                    int rows = square ? uni(step, 2 * step + 10) : uni(step + 1, 3 * step + 50);
+                    if (c == 0) rows = uni(0, step);                                   // not longer than the overlap: ERR_SHAPE
+                    if (c == 1 && !square) rows = uni(step + 1, 2 * step - 1);         // three windows meet: the sequential form
+                    win_rows.push_back(rows);
+                    win_ld.push_back((square ? rows : n_cols) + (uni(0, 4) == 0 ? 4 : 0));
+                }
+                seq_win[s + 1] = seq_win[s] + n;
+            }
+            std::vector<int64_t> sizes(n_seq);
+            int rc = dctfp_stitch_sizes(win_rows.data(), seq_win.data(), n_seq, step, square, sizes.data());
+            if (!ok_or_expected(rc, "dctfp_stitch_sizes")) return 1;
+            if (rc == DCTFP_OK) {
+                std::vector<std::vector<float>> wins(win_rows.size()), outs(n_seq);
+                std::vector<const void*> wp(win_rows.size());
+                std::vector<void*> dp(n_seq);
+                std::vector<int64_t> dld(n_seq);
+                for (size_t w = 0; w < win_rows.size(); ++w) {
+                    wins[w].assign((size_t)std::max<int64_t>(1, win_rows[w] * win_ld[w]), 1.0f);
+                    wp[w] = wins[w].data();
+                }
+                for (int s = 0; s < n_seq; ++s) {
+                    dld[s] = square ? sizes[s] : n_cols;
+                    outs[s].assign((size_t)std::max<int64_t>(1, sizes[s] * dld[s]), 0.0f);
+                    dp[s] = outs[s].data();
+                }
+                if (starve) g_fail_after = uni(0, 8);
+                rc = dctfp_stitch_sequences(ctx, wp.data(), win_rows.data(), win_ld.data(), seq_win.data(), n_seq, dp.data(), dld.data(), n_cols, step, square, nullptr);
+                g_fail_after = -1;
+                if (!ok_or_expected(rc, "dctfp_stitch_sequences")) return 1;
+                // the same windows as explicit jobs (what dctfp_stitch takes), one of them malformed now and then
+                std::vector<dctfp_stitch_job> jobs;
+                for (int s = 0; s < n_seq; ++s)
+                    for (int64_t w = seq_win[s]; w < seq_win[s + 1]; ++w) {
+                        dctfp_stitch_job j{wp[w], dp[s], win_ld[w], dld[s], win_rows[w], w > seq_win[s] ? std::min(step, win_rows[w]) : 0, (int32_t)(w - seq_win[s]), 0};
+                        if (uni(0, 200) == 0) j.n_avg = j.n_rows + 1;
+                        jobs.push_back(j);
+                    }
+                if (starve) g_fail_after = uni(0, 8);
+                rc = dctfp_stitch(ctx, jobs.data(), (int64_t)jobs.size(), n_cols, square, nullptr);
+                g_fail_after = -1;
+                if (!ok_or_expected(rc, "dctfp_stitch")) return 1;
+            }
+        }
+        // ---- similarity consumers: every alignment class of the L1 matrix, block minima, the row select in one segment,
+        // in several (candidate scratch), with k beyond the register kernel
+        {
+            const int na = uni(1, 300), nb = uni(1, 300), d = (int[]){480, 470, 16, 3, 129}[uni(0, 4)];
+            const int64_t lda = d + (int[]){0, 0, 10, 16}[uni(0, 3)], ldb = d + (int[]){0, 0, 6, 16}[uni(0, 3)];
+            std::vector<int8_t> a((size_t)na * lda + 16), b((size_t)nb * ldb + 16);
+            std::vector<int32_t> dist((size_t)na * nb);
+            if (!ok_or_expected(dctfp_l1_matrix(ctx, a.data() + uni(0, 1), na, lda, b.data(), nb, ldb, d, dist.data(), nb, nullptr), "dctfp_l1_matrix")) return 1;
+            std::vector<int64_t> ia{0}, ib{0};
+            while (ia.back() < na) ia.push_back(std::min<int64_t>(na, ia.back() + uni(0, 7)));
+            while (ib.back() < nb) ib.push_back(std::min<int64_t>(nb, ib.back() + uni(0, 7)));
+            std::vector<int32_t> mn((ia.size() - 1) * (ib.size() - 1) + 1), last(mn.size());
+            if (!ok_or_expected(dctfp_block_min(ctx, dist.data(), nb, ia.data(), (int64_t)ia.size() - 1, ib.data(), (int64_t)ib.size() - 1, mn.data(), last.data(),
+                                                nullptr), "dctfp_block_min")) return 1;
+            const int64_t n_rows = uni(1, 20), n_cols = (int64_t[]){1, 50, 40960, 40961, 130000}[uni(0, 4)];
+            const int32_t k = (int32_t)std::min<int64_t>(n_cols, (int64_t[]){1, 100, 1024, 1025, 5000}[uni(0, 4)]);
+            std::vector<int32_t> wide((size_t)n_rows * n_cols), val((size_t)n_rows * k), idx((size_t)n_rows * k);
+            if (starve) g_fail_after = uni(0, 4);
+            const int rc = dctfp_row_select(ctx, wide.data(), n_rows, n_cols, n_cols, k, val.data(), idx.data(), nullptr);
+            g_fail_after = -1;
+            if (!ok_or_expected(rc, "dctfp_row_select")) return 1;
+        }
+    }
+    return 0;
+}
 
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 300;
@@ -192,6 +357,9 @@ int main(int argc, char** argv) {
             for (int s = 0; s < n_seq; ++s) free(data[l][s]);
         }
     }
+    int n_other_calls = 0, n_other_expected = 0;
+    if (other_entry_points(ctx, rng, std::max(20, rounds / 3), &n_other_calls, &n_other_expected)) return 1;
+    printf("the other entry points: %d calls (%d ended in an expected error)\n", n_other_calls, n_other_expected);
     CHECK(dctfp_destroy(ctx));
     printf("allocation failures injected and reported as DCTFP_ERR_NOMEM: %ld\n", g_failed);
     printf("asan driver: %d calls over %d rounds (%d ended in an expected error), %lu walk-kernel launches, %lu stage-A launches, "

@@ -6,7 +6,10 @@ GPU AddressSanitizer is not available on the pool, and a wrong index in a job ta
 device memory = host memory; a kernel launch walks the job tables the way the kernel's waves do and touches every address
 they would) and driven over a few hundred seeded random batches (tests/asan/driver.cpp): every shape class, option,
 fused-group layout, the split at giant domains, failure injection (also std::bad_alloc from any allocation of the table
-build: the C ABI must answer DCTFP_ERR_NOMEM, not std::terminate) and arena restarts of the cosine-table cache."""
+build: the C ABI must answer DCTFP_ERR_NOMEM, not std::terminate) and arena restarts of the cosine-table cache.  Round 4: the
+entry points either side of dctfp_quantize too -- the domain-string parser, the top-k job / stripe tables and sorting-network
+groups, the window jobs of the stitcher in both forms, the L1 matrix / block minima / row select with its candidate scratch
+-- over random and malformed arguments, again with allocation failures injected."""
 
 import os
 import re
@@ -78,3 +81,7 @@ def test_host_code_under_address_sanitizer(tmp_path):
         assert int(re.search(r'reported as DCTFP_ERR_NOMEM: (\d+)', r.stdout).group(1)) >= 10, r.stdout
         walked = int(re.search(r'(\d+) walk-kernel launches', r.stdout).group(1))
         assert walked >= 20, r.stdout          # the production path is among what was exercised
+        # the entry points either side of dctfp_quantize (round 4): domain-string parser, top-k tables, stitch jobs, row select
+        other = re.search(r'the other entry points: (\d+) calls \((\d+) ended in an expected error\)', r.stdout)
+        assert int(other.group(1)) >= 500 and int(other.group(2)) < int(other.group(1)) // 3, r.stdout
+        print(r.stdout.strip().splitlines()[-3:])
