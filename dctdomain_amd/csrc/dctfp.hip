@@ -2145,7 +2145,7 @@ int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_
     const int64_t n_seg = (n_cols + kSeg - 1) / kSeg;
     const bool reg_ok = ctx->opt_row_select != 1 && k <= 1024 && n_rows * n_seg <= 0x7fffffff && (n_seg == 1 || n_seg * k <= kSeg);
     if (reg_ok && n_seg == 1) {
-        hipLaunchKernelGGL((row_select_reg_kernel<kPer, false>), dim3((unsigned)n_rows), dim3(1024), 0, stream, dist, (const int32_t*)nullptr,
+        hipLaunchKernelGGL((row_select_reg_kernel<2 * kPer, false, 512>), dim3((unsigned)n_rows), dim3(512), 0, stream, dist, (const int32_t*)nullptr,
                            ld, n_cols, kSeg, (int64_t)1, (int)k, out_val, out_idx);
     } else if (reg_ok) {
         const int64_t n_in = n_seg * k;                       // candidates per row
@@ -2153,9 +2153,9 @@ int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_
         if (rc) return rc;
         int32_t* cand_val = (int32_t*)ctx->scratch.p;
         int32_t* cand_idx = cand_val + (size_t)n_rows * n_in;
-        hipLaunchKernelGGL((row_select_reg_kernel<kPer, false>), dim3((unsigned)(n_rows * n_seg)), dim3(1024), 0, stream, dist,
+        hipLaunchKernelGGL((row_select_reg_kernel<2 * kPer, false, 512>), dim3((unsigned)(n_rows * n_seg)), dim3(512), 0, stream, dist,
                            (const int32_t*)nullptr, ld, n_cols, kSeg, n_seg, (int)k, cand_val, cand_idx);
-        hipLaunchKernelGGL((row_select_reg_kernel<kPer, true>), dim3((unsigned)n_rows), dim3(1024), 0, stream, (const int32_t*)cand_val,
+        hipLaunchKernelGGL((row_select_reg_kernel<kPer, true, 1024>), dim3((unsigned)n_rows), dim3(1024), 0, stream, (const int32_t*)cand_val,
                            (const int32_t*)cand_idx, n_in, n_in, n_in, (int64_t)1, (int)k, out_val, out_idx);
     } else {
         hipLaunchKernelGGL(row_select_kernel, dim3((unsigned)n_rows), dim3(1024), 0, stream, dist, ld, n_cols, k, out_val, out_idx);

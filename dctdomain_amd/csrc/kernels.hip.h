@@ -2691,7 +2691,7 @@ __device__ inline uint32_t kth_smallest(const uint32_t (&key)[E], uint32_t lo, u
 }
 
 // The kk smallest of E (key, column) pairs per thread, ties to the lowest columns: T = the kk-th smallest key by bisection
-// in [lo, hi] (n_less = count(key < lo) on entry), then emit(key, column) for each of them.  Slots without an entry hold
+// in [lo, hi] (n_less = count(key < lo) on entry), then emit(output slot, key, column) for each of them.  Slots without an entry hold
 // key 0xffffffff and a column > col_hi; `valid(j)` tells them from real entries of that value.
 template <int E, typename ColF, typename ValidF, typename EmitF>
 __device__ inline void bisect_emit(const uint32_t (&key)[E], ColF col_of, ValidF valid, uint32_t lo, uint32_t hi, uint32_t n_less,
@@ -2724,16 +2724,25 @@ __device__ inline void bisect_emit(const uint32_t (&key)[E], ColF col_of, ValidF
         }
         last_col = clo;
     }
+    // output slots: one LDS add per wave and register (the lanes that take an entry rank themselves inside the wave's block)
 #pragma unroll
-    for (int j = 0; j < E; ++j)
-        if (valid(j) && (key[j] < thr || (key[j] == thr && col_of(j) <= last_col))) emit(key[j], col_of(j));
+    for (int j = 0; j < E; ++j) {
+        const bool take = valid(j) && (key[j] < thr || (key[j] == thr && col_of(j) <= last_col));
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(take);
+        if (mask != 0) {   // (wave-uniform)
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&sh.pos, (uint32_t)__builtin_popcountll(mask));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (take) emit(base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)), key[j], col_of(j));
+        }
+    }
 }
 
-template <int PER, bool COLS>
-#ifndef DCTFP_SELECT_WAVES
-#define DCTFP_SELECT_WAVES 4   // waves per SIMD the allocation is held to: 4 = one workgroup per CU; 8 = two, with 20 of the 40 entries spilled: the same rate
-#endif
-__global__ __launch_bounds__(1024, COLS ? 4 : DCTFP_SELECT_WAVES) void row_select_reg_kernel(const int32_t* __restrict__ src_val, const int32_t* __restrict__ src_col,
+// TH threads hold PER entries each (TH * PER = the segment).  1024 x 40 needs 118 registers: one workgroup per CU, whose load
+// and counting phases nobody overlaps; 512 x 80 fits two workgroups per CU at the same 128-register budget, and one loads
+// while the other counts.  Every thread gives 1024 / TH minima (over equal shares of its entries) to the bound.
+template <int PER, bool COLS, int TH>
+__global__ __launch_bounds__(TH, 4) void row_select_reg_kernel(const int32_t* __restrict__ src_val, const int32_t* __restrict__ src_col,
                                                                            int64_t ld, int64_t n_cols, int64_t seg_cols, int64_t n_seg, int k,
                                                                            int32_t* __restrict__ out_val, int32_t* __restrict__ out_idx) {
     __shared__ SelectShared sh;
@@ -2748,45 +2757,51 @@ __global__ __launch_bounds__(1024, COLS ? 4 : DCTFP_SELECT_WAVES) void row_selec
     int32_t* __restrict__ ov = out_val + ((size_t)row * n_seg + seg) * k;
     int32_t* __restrict__ oi = out_idx + ((size_t)row * n_seg + seg) * k;
     const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < 128) sh.cnt[tid] = 0;
+    for (int q = tid; q < 128; q += TH) sh.cnt[q] = 0;
     if (tid == 0) {
         sh.pos = 0;
         sh.fill = 0;
     }
-    // order-preserving keys, smallest first: sign bit flipped.  Element j of thread t is entry j * 1024 + t of the segment.
+    // order-preserving keys, smallest first: sign bit flipped.  Element j of thread t is entry j * TH + t of the segment.
+    constexpr int NMIN = 1024 / TH, SHARE = PER / NMIN;   // minima per thread, entries behind each
+    static_assert(TH * NMIN == 1024 && SHARE * NMIN == PER, "1024 minima over equal shares");
     uint32_t key[PER];
     uint32_t col[COLS ? PER : 1];
-    uint32_t kmin = 0xffffffffu;
+    uint32_t kmin[NMIN];
+#pragma unroll
+    for (int q = 0; q < NMIN; ++q) kmin[q] = 0xffffffffu;
     {   // All loads first, unconditionally: a load under `if (c < n)` is waited for before the next one is issued -- 40 round
         // trips to HBM per wave.  Through a buffer descriptor that ends with the segment: one lane offset for all of them
         // (40 clamped addresses would cost 40 more registers), a slot past the end reads 0 and is overwritten below.
         const __amdgpu_buffer_rsrc_t vb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(v), 0, n * 4, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < PER; ++j) key[j] = __builtin_amdgcn_raw_buffer_load_b32(vb, tid * 4, j * 4096, DCTFP_STREAM_AUX);
+        for (int j = 0; j < PER; ++j) key[j] = __builtin_amdgcn_raw_buffer_load_b32(vb, tid * 4, j * TH * 4, DCTFP_STREAM_AUX);
         if (COLS) {
             const __amdgpu_buffer_rsrc_t cb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(cs), 0, n * 4, 0x00020000);
 #pragma unroll
-            for (int j = 0; j < PER; ++j) col[j] = __builtin_amdgcn_raw_buffer_load_b32(cb, tid * 4, j * 4096, 0);
+            for (int j = 0; j < PER; ++j) col[j] = __builtin_amdgcn_raw_buffer_load_b32(cb, tid * 4, j * TH * 4, 0);
         }
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const bool have = j * 1024 + tid < n;
+            const bool have = j * TH + tid < n;
             key[j] = have ? key[j] ^ 0x80000000u : 0xffffffffu;
             if (COLS) col[j] = have ? col[j] : 0xffffffffu;
-            kmin = min(kmin, key[j]);
+            kmin[j / SHARE] = min(kmin[j / SHARE], key[j]);
         }
     }
-    const int my_n = tid < n ? (n - tid + 1023) / 1024 : 0;  // my entries: j < my_n
-    auto col_of = [&](int j) { return COLS ? col[j] : (uint32_t)(j * 1024 + tid); };   // (segment-local, or as it came)
+    const int my_n = tid < n ? (n - tid + TH - 1) / TH : 0;  // my entries: j < my_n
+    auto col_of = [&](int j) { return COLS ? col[j] : (uint32_t)(j * TH + tid); };   // (segment-local, or as it came)
     const uint32_t col_hi = COLS ? 0x7fffffffu : (uint32_t)(n - 1);
-    auto emit = [&](uint32_t key_e, uint32_t col_e) {
-        const uint32_t pos = atomicAdd(&sh.pos, 1u);
+    auto emit = [&](uint32_t pos, uint32_t key_e, uint32_t col_e) {
         ov[pos] = (int32_t)(key_e ^ 0x80000000u);
         oi[pos] = COLS ? (int32_t)col_e : (int32_t)(c_first + col_e);
     };
-    s_min[tid] = kmin;
+#pragma unroll
+    for (int q = 0; q < NMIN; ++q) s_min[q * TH + tid] = kmin[q];
     __syncthreads();
-    if (tid < 64) {   // 1.: at least kk threads hold an entry (kk <= min(n, 1024)); threads without one sort last
+    if (tid < 64) {   // 1.: the kk-th smallest of the 1024 minima.  With one minimum per thread at least kk of them are real (kk <=
+        // min(n, 1024)); with two, a short segment may fill fewer than kk shares: the bound is then 0xffffffff -- an upper bound
+        // all the same, and what follows tells real entries of that value from empty slots.
         uint32_t lo = 0xffffffffu, hi = 0;   // (the minima stay in LDS: the wave's registers hold its 40 entries)
         for (int i = 0; i < 16; ++i) {
             const uint32_t m = s_min[i * 64 + lane];
@@ -2837,20 +2852,20 @@ __global__ __launch_bounds__(1024, COLS ? 4 : DCTFP_SELECT_WAVES) void row_selec
             }
         }
         __syncthreads();
-        constexpr int E = kSelectCap / 1024;
+        constexpr int E = kSelectCap / TH;
         uint32_t ck[E], cc[E];
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const uint32_t e = (uint32_t)(i * 1024 + tid);
+            const uint32_t e = (uint32_t)(i * TH + tid);
             ck[i] = e < below ? s_ckey[e] : 0xffffffffu;
             cc[i] = e < below ? s_ccol[e] : 0xffffffffu;
         }
-        bisect_emit<E>(ck, [&](int i) { return cc[i]; }, [&](int i) { return (uint32_t)(i * 1024 + tid) < below; }, row_min, bound - 1u, 0u,
+        bisect_emit<E>(ck, [&](int i) { return cc[i]; }, [&](int i) { return (uint32_t)(i * TH + tid) < below; }, row_min, bound - 1u, 0u,
                        col_hi, kk, sh, step, emit);
     } else {                                   // a row of few distinct values
         bisect_emit<PER>(key, col_of, [&](int j) { return j < my_n; }, row_min, bound - 1u, 0u, col_hi, kk, sh, step, emit);
     }
-    for (uint32_t pos = kk + (uint32_t)tid; pos < (uint32_t)k; pos += 1024) {   // a segment shorter than k: candidates that lose every tie
+    for (uint32_t pos = kk + (uint32_t)tid; pos < (uint32_t)k; pos += TH) {   // a segment shorter than k: candidates that lose every tie
         ov[pos] = 0x7fffffff;
         oi[pos] = 0x7fffffff;
     }
@@ -2963,8 +2978,7 @@ __device__ inline void topk2_run(const TopkJob& job, SelectShared& sh, uint32_t*
     int32_t* __restrict__ oj = out_j + job.out_off;
     float* __restrict__ ov = out_v + job.out_off;
     bisect_emit<E>(ck, [&](int e) { return cij[e]; }, [&](int e) { return (uint32_t)(e * 1024 + tid) < n_cand; }, 0u, bound, 0u, 0xfffffffeu, kk, sh,
-                   step, [&](uint32_t, uint32_t ij) {
-                       const uint32_t pos = atomicAdd(&sh.pos, 1u);
+                   step, [&](uint32_t pos, uint32_t, uint32_t ij) {
                        const int i = (int)(ij >> 16), j = (int)(ij & 0xffffu);
                        oi[pos] = i;
                        oj[pos] = j;
