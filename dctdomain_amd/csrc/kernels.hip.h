@@ -2644,14 +2644,15 @@ __global__ __launch_bounds__(1024) void row_select_kernel(const int32_t* __restr
 #endif
 
 
-// The same selection with the row held in registers (round 4): one workgroup of 1024 threads loads up to 1024 * PER entries
+// The same selection with the row held in registers (round 4): one workgroup of TH threads loads up to TH * PER entries
 // ONCE (the radix select above reads its row six times and counts through LDS atomics that all hit a few bins: 2.6 ms for
-// 6 700 rows of 40 000 against 1.2 ms for the distance matrix itself).
-//   1. every thread keeps the minimum of its PER entries; the k-th smallest of those 1024 minima, B, is an upper bound of the
-//      k-th smallest entry T (the minima are a subset of the row) -- found by one wave, 16 minima per lane, by bisection;
+// 6 700 rows of 40 000 against 1.2 ms for the distance matrix itself; this kernel: 0.34 ms).
+//   1. every thread keeps the minimum of each of its 1024 / TH equal shares of entries; the k-th smallest of those 1024 minima,
+//      B, is an upper bound of the k-th smallest entry T (the minima are a subset of the row) -- found by one wave, 16 minima
+//      per lane, by bisection;
 //   2. one compare per register counts the entries below B.  Fewer than k: T = B, and the entries below B plus the first
 //      ties at B (by column) are the answer.  Else the entries below B -- a few more than k -- move to LDS with their columns,
-//   3. and T is found among those by bisection on the value, 4 per thread (count = the compare's lane mask, popcount on the
+//   3. and T is found among those by bisection on the value, kSelectCap / TH per thread (count = the compare's lane mask, popcount on the
 //      scalar unit, one LDS add per wave and step); where more entries equal T than are still wanted, the last column to
 //      take by bisection on the column.  More than kSelectCap entries below B (a row of few distinct values): the same
 //      bisection over the registers themselves.
