@@ -53,7 +53,7 @@ _lib_lock = threading.Lock()
 
 EXPORTS = ('dctfp_version', 'dctfp_last_error', 'dctfp_create', 'dctfp_destroy', 'dctfp_quantize',
            'dctfp_idct_quant', 'dctfp_scale', 'dctfp_gather_rows', 'dctfp_contact_topk',
-           'dctfp_contact_count', 'dctfp_stitch', 'dctfp_l1_matrix', 'dctfp_block_min', 'dctfp_row_select', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile', 'dctfp_host_device_pointer',
+           'dctfp_contact_count', 'dctfp_stitch', 'dctfp_l1_matrix', 'dctfp_block_min', 'dctfp_row_select', 'dctfp_row_order', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile', 'dctfp_host_device_pointer',
            'dctfp_stream_synchronize', 'dctfp_runtime_info', 'dctfp_crash_handler', 'dctfp_build_pieces', 'dctfp_contact_sort', 'dctfp_stitch_sizes',
            'dctfp_stitch_sequences')
 
@@ -153,6 +153,7 @@ def _configure(lib):
                                         C.c_void_p, C.c_void_p, C.c_void_p]
         lib.dctfp_row_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
                                          C.c_void_p, C.c_void_p]
+        lib.dctfp_row_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         lib.dctfp_stitch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
         lib.dctfp_stitch_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
         lib.dctfp_stitch_sequences.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,

@@ -2164,6 +2164,22 @@ int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_
     return DCTFP_OK;
 } DCTFP_GUARD("dctfp_row_select")
 
+int dctfp_row_order(dctfp_ctx* ctx, int32_t* val, int32_t* idx, int64_t n_rows, int32_t k, void* stream_v) try {
+    if (!ctx || !val || !idx) return fail(DCTFP_ERR_INVALID, "dctfp_row_order: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_rows < 0 || k < 1) return fail(DCTFP_ERR_INVALID, "dctfp_row_order: bad shape");
+    if (k > 1024) return fail(DCTFP_ERR_LIMIT, "dctfp_row_order: more than 1024 entries per row (order them on the host)");
+    if (n_rows > 0x7fffffff) return fail(DCTFP_ERR_LIMIT, "dctfp_row_order: too many rows");
+    if (n_rows == 0 || k == 1) return DCTFP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (k <= 128) hipLaunchKernelGGL((row_order_kernel<128>), dim3((unsigned)n_rows), dim3(64), 0, stream, val, idx, (int)k);
+    else if (k <= 256) hipLaunchKernelGGL((row_order_kernel<256>), dim3((unsigned)n_rows), dim3(128), 0, stream, val, idx, (int)k);
+    else hipLaunchKernelGGL((row_order_kernel<1024>), dim3((unsigned)n_rows), dim3(512), 0, stream, val, idx, (int)k);
+    HIP_TRY(hipGetLastError());
+    return DCTFP_OK;
+} DCTFP_GUARD("dctfp_row_order")
+
 int dctfp_host_device_pointer(void* host, void** dev) try {
     if (!host || !dev) return fail(DCTFP_ERR_INVALID, "dctfp_host_device_pointer: NULL argument");
     *dev = nullptr;

@@ -2873,6 +2873,38 @@ __global__ __launch_bounds__(TH, 4) void row_select_reg_kernel(const int32_t* __
 }
 
 
+// The k entries a row select left for a row, in the order a flat index scan reports them: value ascending, ties by column
+// (round 4: numpy's lexsort of 6 700 x 100 survivors took 134 ms, and as long again to apply -- against 1.5 ms for the distance
+// matrix and the selection together).  One workgroup of N / 2 threads per row: 64-bit keys (order-preserving value above the
+// column) through a bitonic network in LDS, written back in place.  N = capacity (a power of two >= k).
+template <int N>
+__global__ __launch_bounds__(N / 2) void row_order_kernel(int32_t* __restrict__ val, int32_t* __restrict__ idx, int k) {
+    __shared__ unsigned long long keys[N];
+    int32_t* __restrict__ v = val + (size_t)blockIdx.x * k;
+    int32_t* __restrict__ c = idx + (size_t)blockIdx.x * k;
+    for (int p = threadIdx.x; p < N; p += N / 2)
+        keys[p] = p < k ? ((unsigned long long)((uint32_t)v[p] ^ 0x80000000u) << 32) | (uint32_t)c[p] : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= N; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int q = threadIdx.x;
+            const int lo = ((q & ~(stride - 1)) << 1) | (q & (stride - 1));
+            const int hi = lo | stride;
+            const bool up = (lo & size) == 0;
+            const unsigned long long a = keys[lo], b = keys[hi];
+            if ((a > b) == up) {
+                keys[lo] = b;
+                keys[hi] = a;
+            }
+            __syncthreads();
+        }
+    }
+    for (int p = threadIdx.x; p < k; p += N / 2) {
+        v[p] = (int32_t)((uint32_t)(keys[p] >> 32) ^ 0x80000000u);
+        c[p] = (int32_t)(uint32_t)keys[p];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Contact top-k in two reads of the map (round 4; contact_topk_kernel above reads it six times and counts through LDS
 // atomics that mostly hit one bin).  Keys are the inverted order-preserving images of the values, so "largest value first,

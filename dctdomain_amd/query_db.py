@@ -17,7 +17,7 @@ from io import BytesIO
 import numpy as np
 
 from .database import Database
-from .similarity import l1_matrix, row_select, to_device_int8
+from .similarity import l1_matrix, order_pairs, row_select, to_device_int8
 
 
 def _load_all(db: Database):
@@ -63,9 +63,8 @@ def search(query_rows, query_fps, db_rows, db_fps, khits: int):
     if len(cand_d) == 1:
         dm, im = cand_d[0], cand_i[0]
     elif cand_d:
-        v, i = np.concatenate(cand_d, axis=1), np.concatenate(cand_i, axis=1)
-        order = np.lexsort((i, v), axis=1)[:, :k]
-        dm, im = np.take_along_axis(v, order, axis=1), np.take_along_axis(i, order, axis=1)
+        dm, im = order_pairs(np.concatenate(cand_d, axis=1), np.concatenate(cand_i, axis=1))
+        dm, im = dm[:, :k], im[:, :k]
     else:
         dm, im = np.zeros((nq, 0), np.int64), np.zeros((nq, 0), np.int64)
     by_pid = {}
@@ -73,9 +72,12 @@ def search(query_rows, query_fps, db_rows, db_fps, khits: int):
         by_pid.setdefault(r[1], []).append(qi)
     for pid in sorted(by_pid):
         qis = by_pid[pid]
-        items = [((i, j), dm[qi, j]) for i, qi in enumerate(qis) for j in range(k)]
-        items.sort(key=lambda x: x[1])
-        for rank, ((i, j), d) in enumerate(items[:khits]):
+        # all hits of the protein's fingerprints ranked by distance, stable in (fingerprint, hit) order -- the reference's
+        # list.sort(key=distance) over the items as it appends them (:52-59)
+        d_all = dm[qis].ravel()
+        for rank, flat in enumerate(np.argsort(d_all, kind='stable')[:khits].tolist()):
+            i, j = divmod(flat, k)
+            d = d_all[flat]                                    # (a numpy scalar, as before: round() of it is numpy's)
             qrow = query_rows[qis[i]]
             drow = db_rows[im[qis[i], j]]
             score = round(1 - (d / 17000), 4)

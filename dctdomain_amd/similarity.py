@@ -4,6 +4,7 @@ arithmetic under the reference's two consumers, ``src/dct-sim.py`` and ``src/que
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -61,22 +62,49 @@ def block_min(dist: torch.Tensor, idx_a, idx_b):
                                             dist.stride(0) if dist.shape[0] > 1 else dist.shape[1], ia.data_ptr(), npa,
                                             ib.data_ptr(), npb, mn.data_ptr(), last.data_ptr(),
                                             C.c_void_p(stream.cuda_stream)))
-    return mn.cpu().numpy(), last.cpu().numpy()
+    return _pair_to_host(mn, last, np.int32)
+
+
+def order_pairs(v: np.ndarray, i: np.ndarray):
+    """(values, indices) with every row ordered by (value, index): one sort of packed 64-bit keys instead of ``np.lexsort``
+    along an axis (134 ms for 6 700 x 100 pairs, and as long again to apply; this: 5 ms).  int32-range values, indices < 2^32."""
+    key = ((v.astype(np.int64) + (1 << 31)).astype(np.uint64) << np.uint64(32)) | i.astype(np.uint64)
+    key.sort(axis=1)
+    return (key >> np.uint64(32)).astype(np.int64) - (1 << 31), (key & np.uint64(0xffffffff)).astype(np.int64)
 
 
 def row_select(dist: torch.Tensor, k: int):
     """(values, indices) numpy arrays (n_rows, k): the k smallest entries of each row, ascending, ties
-    to the lower column -- selected on the GPU (``dctfp_row_select``), the k survivors ordered on the host."""
+    to the lower column -- selected (``dctfp_row_select``) and ordered (``dctfp_row_order``, k <= 1024) on the GPU."""
     n_rows, n_cols = dist.shape
     k = min(int(k), n_cols)
     val = torch.empty((n_rows, k), dtype=torch.int32, device=dist.device)
     idx = torch.empty((n_rows, k), dtype=torch.int32, device=dist.device)
+    on_device = k <= 1024
     if n_rows:
         ctx = _lib.get_context(dist.device.index)
-        stream = torch.cuda.current_stream(dist.device)
+        stream = C.c_void_p(torch.cuda.current_stream(dist.device).cuda_stream)
         _lib.check(ctx._lib.dctfp_row_select(ctx.handle, dist.data_ptr(), n_rows, n_cols,
-                                             dist.stride(0) if n_rows > 1 else n_cols, k, val.data_ptr(), idx.data_ptr(),
-                                             C.c_void_p(stream.cuda_stream)))
-    v, i = val.cpu().numpy().astype(np.int64), idx.cpu().numpy().astype(np.int64)
-    order = np.lexsort((i, v), axis=1)
-    return np.take_along_axis(v, order, axis=1), np.take_along_axis(i, order, axis=1)
+                                             dist.stride(0) if n_rows > 1 else n_cols, k, val.data_ptr(), idx.data_ptr(), stream))
+        if on_device:
+            _lib.check(ctx._lib.dctfp_row_order(ctx.handle, val.data_ptr(), idx.data_ptr(), n_rows, k, stream))
+    v, i = _pair_to_host(val, idx)
+    return (v, i) if on_device else order_pairs(v, i)
+
+
+_PINNED = threading.local()
+
+
+def _pair_to_host(val: torch.Tensor, idx: torch.Tensor, dtype=np.int64):
+    """Two int32 device tensors of one shape -> numpy arrays through one page-locked staging buffer of this thread (a pageable
+    ``.cpu()`` of a tile's 2 x 2.7 MB took 18 ms each on the GPU boxes; this: both in under a millisecond)."""
+    n = val.numel()
+    pin = getattr(_PINNED, 'buf', None)
+    if pin is None or pin.numel() < 2 * n:
+        pin = torch.empty(max(2 * n + n // 2, 1 << 18), dtype=torch.int32, pin_memory=True)
+        _PINNED.buf = pin
+    pin[:n].view(val.shape).copy_(val, non_blocking=True)
+    pin[n:2 * n].view(idx.shape).copy_(idx, non_blocking=True)
+    torch.cuda.current_stream(val.device).synchronize()
+    host = pin[:2 * n].numpy().astype(dtype)                    # (the copy out of the staging buffer, and the widening, in one)
+    return host[:n].reshape(val.shape), host[n:].reshape(idx.shape)

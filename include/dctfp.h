@@ -225,6 +225,11 @@ int dctfp_block_min(dctfp_ctx* ctx, const int32_t* dist, int64_t ldo, const int6
 int dctfp_row_select(dctfp_ctx* ctx, const int32_t* dist, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k,
                      int32_t* out_val, int32_t* out_idx, void* stream);
 
+/* Orders what dctfp_row_select left, in place and on the device: each row's k (value, column) pairs ascending by value, ties by
+ * column -- the order in which a flat L1 index reports its hits (src/query_db.py:87).  k <= 1024 (DCTFP_ERR_LIMIT beyond:
+ * order those on the host). */
+int dctfp_row_order(dctfp_ctx* ctx, int32_t* val, int32_t* idx, int64_t n_rows, int32_t k, void* stream);
+
 /* The address under which the GPU sees a pinned (page-locked, mapped) host buffer, e.g. a torch tensor created with
  * pin_memory=True.  A caller that passes this address as `out` of dctfp_quantize gets the int8 result written straight
  * into host memory: no device buffer, no copy -- what a one-protein-per-call user wants (480 bytes per domain). */

@@ -220,6 +220,7 @@ static int other_entry_points(dctfp_ctx* ctx, std::mt19937_64& rng, int rounds, 
             const int rc = dctfp_row_select(ctx, wide.data(), n_rows, n_cols, n_cols, k, val.data(), idx.data(), nullptr);
             g_fail_after = -1;
             if (!ok_or_expected(rc, "dctfp_row_select")) return 1;
+            if (!ok_or_expected(dctfp_row_order(ctx, val.data(), idx.data(), n_rows, k, nullptr), "dctfp_row_order")) return 1;   // (k > 1024: the limit error)
         }
     }
     return 0;

@@ -243,3 +243,18 @@ def test_runtime_report_and_crash_handler_exports():
     assert lib.dctfp_crash_handler(1) == 0 and lib.dctfp_crash_handler(0) == 0
     if os.environ.get('DCTFP_CRASH_BACKTRACE') == '1':
         assert lib.dctfp_crash_handler(1) == 0      # (leave it as conftest asked for it)
+
+
+def test_order_pairs_is_lexsort_by_value_then_index():
+    """similarity.order_pairs (one sort of packed 64-bit keys; what orders more than 1024 survivors per row and the candidates of
+    several database blocks) against np.lexsort, the whole int32 range of values, ties included."""
+    from dctdomain_amd.similarity import order_pairs
+    rng = np.random.default_rng(12)
+    for span in (3, 1000, 2**31 - 1):
+        v = rng.integers(-span, span, size=(50, 300)).astype(np.int64)
+        v[:, :4] = np.array([-2**31, 2**31 - 1, -2**31, 2**31 - 1])
+        i = np.stack([rng.permutation(2**20)[:300] for _ in range(50)]).astype(np.int64)
+        order = np.lexsort((i, v), axis=1)
+        a, b = order_pairs(v, i)
+        np.testing.assert_array_equal(a, np.take_along_axis(v, order, axis=1))
+        np.testing.assert_array_equal(b, np.take_along_axis(i, order, axis=1))

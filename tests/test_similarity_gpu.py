@@ -170,14 +170,14 @@ def test_row_select_in_registers_segments_ties_and_extremes():
 
 
 def test_row_select_random_shapes():
-    """40 random (columns, k, value range) draws around the register kernel's limits: 1 .. 3 segments, k up to 1024, value
+    """60 random (columns, k, value range) draws around the register kernel's limits: 1 .. 3 segments, k up to 1024, value
     ranges from 2 (everything ties) to the whole int32 range -- against numpy's stable argsort."""
     import torch
     from dctdomain_amd.similarity import row_select
     rng = np.random.default_rng(23)
-    for _ in range(40):
+    for _ in range(60):
         n_cols = int(rng.choice([1, 2, 63, 64, 65, 1023, 1024, 1025, 4097, 40959, 40960, 40961, 81920, 81921, int(rng.integers(1, 120000))]))
-        k = int(min(n_cols, rng.choice([1, 2, 10, 100, 1000, 1024, int(rng.integers(1, 1025))])))
+        k = int(min(n_cols, rng.choice([1, 2, 10, 100, 128, 129, 200, 256, 257, 1000, 1024, int(rng.integers(1, 1025))])))   # (ordering networks of 128 / 256 / 1024)
         span = int(rng.choice([2, 3, 17, 1000, 122400, 2**31 - 1]))
         lo = int(rng.integers(-2**31, 2**31 - span))
         d = (rng.integers(0, span, size=(2, n_cols)) + lo).astype(np.int32)

@@ -52,3 +52,19 @@ def bm():
 t = timed(bm)
 ref = dist[:npa * 4, :npb * 4].reshape(npa, 4, npb, 4).amin(dim=(1, 3))
 print(f'block_min {npa} x {npb} blocks of 4 x 4: {1e3 * t:.3f} ms = {nq * nd * 4 / t / 1e9:.0f} GB/s of the matrix; equal to torch: {bool((ref == mn).all())}', flush=True)
+# the search as query_db makes it for one tile: matrix, selection, order, one copy to the host -- against the order on the host
+from dctdomain_amd.similarity import row_select, order_pairs
+t = timed(lambda: row_select(dist, 100), reps=3)
+print(f'row_select + row_order + D2H (similarity.row_select, k = 100): {1e3 * t:.2f} ms per tile', flush=True)
+val = torch.empty((nq, 100), dtype=torch.int32, device=dev); idx = torch.empty((nq, 100), dtype=torch.int32, device=dev)
+_lib.check(ctx._lib.dctfp_row_select(ctx.handle, dist.data_ptr(), nq, nd, dist.stride(0), 100, val.data_ptr(), idx.data_ptr(), C.c_void_p(stream.cuda_stream)))
+torch.cuda.synchronize()
+hv, hi = val.cpu().numpy().astype(np.int64), idx.cpu().numpy().astype(np.int64)
+t0 = time.perf_counter(); order = np.lexsort((hi, hv), axis=1); a = np.take_along_axis(hv, order, axis=1); b = np.take_along_axis(hi, order, axis=1); t_lex = time.perf_counter() - t0
+t0 = time.perf_counter(); a2, b2 = order_pairs(hv, hi); t_pack = time.perf_counter() - t0
+gv, gi = row_select(dist, 100)
+print(f'the same order on the host: np.lexsort + take_along_axis {1e3 * t_lex:.1f} ms (round 3), packed 64-bit keys {1e3 * t_pack:.1f} ms; '
+      f'all three equal: {bool((a == a2).all() and (b == b2).all() and (a == gv).all() and (b == gi).all())}', flush=True)
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable(); row_select(dist, 100); pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(10)
