@@ -75,12 +75,12 @@ def search(query_rows, query_fps, db_rows, db_fps, khits: int):
         # all hits of the protein's fingerprints ranked by distance, stable in (fingerprint, hit) order -- the reference's
         # list.sort(key=distance) over the items as it appends them (:52-59)
         d_all = dm[qis].ravel()
-        for rank, flat in enumerate(np.argsort(d_all, kind='stable')[:khits].tolist()):
-            i, j = divmod(flat, k)
-            d = d_all[flat]                                    # (a numpy scalar, as before: round() of it is numpy's)
+        sel = np.argsort(d_all, kind='stable')[:khits]
+        scores = np.round(1 - (d_all[sel] / 17000), 4).tolist()    # round(1 - (d / 17000), 4) of numpy scalars, :57, all at once
+        ii, jj = np.divmod(sel, k)
+        for rank, (i, j, score) in enumerate(zip(ii.tolist(), jj.tolist(), scores)):
             qrow = query_rows[qis[i]]
             drow = db_rows[im[qis[i], j]]
-            score = round(1 - (d / 17000), 4)
             yield f'Query: {qrow[1]} {qrow[2]}, Result {rank + 1}: {drow[1]} {drow[2]}, Similarity: {score}'
 
 
