@@ -141,13 +141,19 @@ void split_two(int cuts1, int cuts2, const Domain& segs, const std::vector<int>&
 }
 
 // Sum of n weights.  Bytes go 16 at a time through psadbw (SSE2: part of every x86-64).
+// The last 1..15 bytes come in one masked 16-byte load (every buffer handed in here is followed by 16 readable bytes): a
+// scalar tail was most of the time of a 150-byte range.
+alignas(16) static const uint8_t kTailMask[32] = {255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255, 255,
+                                                   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0};
 inline int sum_range(const uint8_t* p, int n) {
     __m128i acc = _mm_setzero_si128();
     int j = 0;
     for (; j + 16 <= n; j += 16) acc = _mm_add_epi64(acc, _mm_sad_epu8(_mm_loadu_si128((const __m128i*)(p + j)), _mm_setzero_si128()));
-    int s = _mm_cvtsi128_si32(acc) + _mm_cvtsi128_si32(_mm_srli_si128(acc, 8));
-    for (; j < n; ++j) s += p[j];
-    return s;
+    if (j < n) {
+        const __m128i m = _mm_loadu_si128((const __m128i*)(kTailMask + 16 - (n - j)));
+        acc = _mm_add_epi64(acc, _mm_sad_epu8(_mm_and_si128(_mm_loadu_si128((const __m128i*)(p + j)), m), _mm_setzero_si128()));
+    }
+    return _mm_cvtsi128_si32(acc) + _mm_cvtsi128_si32(_mm_srli_si128(acc, 8));
 }
 inline int sum_range(const int32_t* p, int n) {
     int s = 0;
@@ -183,9 +189,15 @@ void cut_rec(const Ctx<W>& cx, const std::vector<int>& idx, const std::vector<in
     const int V = (int)idx.size();
     if (V < kMinSize) throw Undefined();  // the binary prints "Protein has length of 0" and exits (-1)
 
-    // local dense copy in current vertex order
-    std::vector<W> a((size_t)V * V);
-    {
+    // The weights in current vertex order: where the vertices are one run of consecutive residues (the whole protein, both
+    // sides of a single cut, the middle of a double cut) that is a window of the graph itself -- rows n0 apart, no copy;
+    // otherwise (the two flanks of a double cut joined) a local dense copy.
+    const bool window = idx[V - 1] - idx[0] == V - 1;
+    std::vector<W> copy;
+    const W* a = window ? &cx.w[(size_t)idx[0] * cx.n0 + idx[0]] : nullptr;
+    const size_t lda = window ? (size_t)cx.n0 : (size_t)V;
+    if (!window) {
+        copy.resize((size_t)V * V + 16);   // (+16: see sum_range)
         // idx is a handful of runs of consecutive residues: copy run by run instead of element by element
         std::vector<std::pair<int, int>> runs;  // (first position in idx, length)
         for (int j = 0; j < V;) {
@@ -196,15 +208,16 @@ void cut_rec(const Ctx<W>& cx, const std::vector<int>& idx, const std::vector<in
         }
         for (int i = 0; i < V; ++i) {
             const W* row = &cx.w[(size_t)idx[i] * cx.n0];
-            W* dst = &a[(size_t)i * V];
+            W* dst = &copy[(size_t)i * V];
             for (const auto& r : runs) std::memcpy(dst + r.first, row + idx[r.first], (size_t)r.second * sizeof(W));
         }
+        a = copy.data();
     }
 
     std::vector<int> pre(V, 0), post(V, 0);
     int sum = 0;
     for (int i = 0; i < V; ++i) {
-        const W* ai = &a[(size_t)i * V];
+        const W* ai = a + (size_t)i * lda;
         const int p = sum_range(ai, i), q = sum_range(ai + i + 1, V - i - 1);
         pre[i] = p;
         post[i] = q;
@@ -253,7 +266,7 @@ void cut_rec(const Ctx<W>& cx, const std::vector<int>& idx, const std::vector<in
         const int nrow = std::min(4, ib - kMinTerminal);          // rows ib-1 .. ib-nrow
         const W* ar[4];
         int r[4] = {0, 0, 0, 0};
-        for (int k = 0; k < nrow; ++k) ar[k] = &a[(size_t)(ib - 1 - k) * V];
+        for (int k = 0; k < nrow; ++k) ar[k] = a + (size_t)(ib - 1 - k) * lda;
         for (int k = 1; k < nrow; ++k) {                          // the entries left of column ib: a few per row
             const int i = ib - 1 - k;
             for (int j = i + 1; j < ib; ++j) {
@@ -348,8 +361,8 @@ void cut_rec(const Ctx<W>& cx, const std::vector<int>& idx, const std::vector<in
         idx2.assign(idx.begin() + cuts1, idx.begin() + cuts2);
         split_two(cuts1, cuts2, segs, sites, V, d1, d2, s1, s2);
     }
-    a.clear();
-    a.shrink_to_fit();
+    copy.clear();
+    copy.shrink_to_fit();
     rows.clear();
     rows.shrink_to_fit();
     cut_rec(cx, idx1, s1, d1, out);
@@ -376,7 +389,7 @@ int cut_protein(int32_t n_res, const int32_t* ci, const int32_t* cj, const int32
     cx.n0 = n_res;
     cx.cut1 = cut1;
     cx.cut2 = cut2;
-    cx.w.assign((size_t)n_res * n_res, 0);
+    cx.w.assign((size_t)n_res * n_res + 16, 0);   // (+16: sum_range's last load may reach past the last row)
     for (int64_t k = 0; k < n_contacts; ++k) {
         const int i = ci[k], j = cj[k];
         cx.w[(size_t)i * n_res + j] = (W)wgt[k];
