@@ -33,6 +33,19 @@ COL_ROWS = 1 << 22      # database fingerprints on the device at a time (2 GB of
 TILE_INTS = 1 << 28     # int32 entries of one distance matrix (1 GiB)
 
 
+def ranked_hits(d_rows: np.ndarray, khits: int):
+    """The first ``khits`` of all hits of one query protein -- ``d_rows[i, j]`` = distance of hit j of its fingerprint i --
+    ranked by distance, stable in (fingerprint, hit) order: the reference's ``sorted(top_hits.items(), key=distance)`` over
+    the items as it inserts them (src/query_db.py:33-40).  Returns (fingerprint index, hit index, score) lists, the scores
+    as ``round(1 - (d / 17000), 4)`` of numpy scalars (:57), rounded all at once."""
+    k = d_rows.shape[1]
+    d_all = d_rows.ravel()
+    sel = np.argsort(d_all, kind='stable')[:khits]
+    scores = np.round(1 - (d_all[sel] / 17000), 4).tolist()
+    ii, jj = np.divmod(sel, k)
+    return ii.tolist(), jj.tolist(), scores
+
+
 def search(query_rows, query_fps, db_rows, db_fps, khits: int):
     """Yields the reference's log lines.  Per query protein (pids in the order ``SELECT pid FROM
     sequences`` returns them: by primary key, i.e. sorted): the ``khits`` nearest database
@@ -74,11 +87,8 @@ def search(query_rows, query_fps, db_rows, db_fps, khits: int):
         qis = by_pid[pid]
         # all hits of the protein's fingerprints ranked by distance, stable in (fingerprint, hit) order -- the reference's
         # list.sort(key=distance) over the items as it appends them (:52-59)
-        d_all = dm[qis].ravel()
-        sel = np.argsort(d_all, kind='stable')[:khits]
-        scores = np.round(1 - (d_all[sel] / 17000), 4).tolist()    # round(1 - (d / 17000), 4) of numpy scalars, :57, all at once
-        ii, jj = np.divmod(sel, k)
-        for rank, (i, j, score) in enumerate(zip(ii.tolist(), jj.tolist(), scores)):
+        ii, jj, scores = ranked_hits(dm[qis], khits)
+        for rank, (i, j, score) in enumerate(zip(ii, jj, scores)):
             qrow = query_rows[qis[i]]
             drow = db_rows[im[qis[i], j]]
             yield f'Query: {qrow[1]} {qrow[2]}, Result {rank + 1}: {drow[1]} {drow[2]}, Similarity: {score}'

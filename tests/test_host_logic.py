@@ -258,3 +258,22 @@ def test_order_pairs_is_lexsort_by_value_then_index():
         a, b = order_pairs(v, i)
         np.testing.assert_array_equal(a, np.take_along_axis(v, order, axis=1))
         np.testing.assert_array_equal(b, np.take_along_axis(i, order, axis=1))
+
+
+def test_ranked_hits_is_the_reference_list_sort():
+    """query_db.ranked_hits (one stable argsort, scores rounded at once) against the reference's own bookkeeping: a dict of
+    (fingerprint, hit) -> distance filled in that order, sorted by distance (Python's stable sort), the first khits, each score
+    ``round(1 - (d / 17000), 4)`` of a numpy scalar -- ties in every position, distances beyond 17 000 (negative scores)."""
+    from dctdomain_amd.query_db import ranked_hits
+    rng = np.random.default_rng(31)
+    for n_fp, k, khits, span in ((1, 1, 1, 5), (3, 7, 10, 4), (5, 100, 100, 30000), (4, 50, 500, 3), (2, 100, 50, 122400)):
+        d = np.sort(rng.integers(0, span, size=(n_fp, k)), axis=1).astype(np.int64)      # rows ascending, as a flat index returns them
+        top_hits = {}
+        for i, row in enumerate(d):
+            for j, dist in enumerate(row):
+                top_hits[i, j] = dist
+        ref = list(dict(sorted(top_hits.items(), key=lambda x: x[1])).keys())[:khits]
+        ii, jj, scores = ranked_hits(d, khits)
+        assert list(zip(ii, jj)) == ref
+        assert [str(s) for s in scores] == [str(round(1 - (top_hits[key] / 17000), 4)) for key in ref]
+
