@@ -21,6 +21,7 @@ DCTFP_ERR_SHAPE = -2
 DCTFP_ERR_HIP = -3
 DCTFP_ERR_NOMEM = -4
 DCTFP_ERR_LIMIT = -5
+DCTFP_ERR_UNSUPPORTED = -6
 DCTFP_MAX_N = 8
 DCTFP_MAX_M = 128
 DCTFP_F32 = 0
@@ -55,7 +56,7 @@ EXPORTS = ('dctfp_version', 'dctfp_last_error', 'dctfp_create', 'dctfp_destroy',
            'dctfp_idct_quant', 'dctfp_scale', 'dctfp_gather_rows', 'dctfp_contact_topk',
            'dctfp_contact_count', 'dctfp_stitch', 'dctfp_l1_matrix', 'dctfp_block_min', 'dctfp_row_select', 'dctfp_row_order', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile', 'dctfp_host_device_pointer',
            'dctfp_stream_synchronize', 'dctfp_runtime_info', 'dctfp_crash_handler', 'dctfp_build_pieces', 'dctfp_contact_sort', 'dctfp_stitch_sizes',
-           'dctfp_stitch_sequences')
+           'dctfp_stitch_sequences', 'dctfp_quantize_windows')
 
 
 def load(path: str = None):
@@ -137,6 +138,8 @@ def _configure(lib):
         lib.dctfp_destroy.argtypes = [C.c_void_p]
         lib.dctfp_quantize.argtypes = [C.c_void_p, C.POINTER(Layer), C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+        lib.dctfp_quantize_windows.argtypes = [C.c_void_p, C.POINTER(Layer), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                               C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
         lib.dctfp_idct_quant.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.dctfp_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]

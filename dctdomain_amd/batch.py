@@ -229,6 +229,82 @@ def host_pointer(t: torch.Tensor) -> int:
     return dev.value
 
 
+def _layer_array(layers: Sequence[LayerBatch], n_data: int):
+    arr = (_lib.Layer * len(layers))()
+    off = 0
+    for i, l in enumerate(layers):
+        if len(l.ptrs) != n_data:
+            raise ValueError(f'layer {i} has {len(l.ptrs)} matrices, the call speaks of {n_data}')
+        arr[i].seq_data = C.cast(C.c_void_p(l.ptrs.ctypes.data), C.POINTER(C.c_void_p))
+        arr[i].ld = l.ld
+        arr[i].n_cols = l.n_cols
+        arr[i].dtype = l.dtype
+        arr[i].n_keep = l.n_keep
+        arr[i].m_keep = l.m_keep
+        arr[i].out_offset = off
+        off += l.n_keep * l.m_keep
+    return arr
+
+
+def window_geometry(win_rows, win_counts, overlap: int = 200):
+    """(seq_win, stitched rows per sequence) of sequences given as windows: ``dctfp_stitch_sizes`` (the reference's
+    ``run[-olp:] = (run[-olp:] + new[:olp]) / 2; cat(new[olp:])``, src/embedding.py:185-187).  ValueError where torch would
+    fail to broadcast there."""
+    win_rows = np.ascontiguousarray(np.asarray(win_rows, dtype=np.int32))
+    counts = np.asarray(win_counts, dtype=np.int64)
+    seq_win = np.zeros(len(counts) + 1, dtype=np.int64)
+    np.cumsum(counts, out=seq_win[1:])
+    if seq_win[-1] != len(win_rows):
+        raise ValueError(f'{len(win_rows)} windows, the sequences count {int(seq_win[-1])}')
+    sizes = np.empty(len(counts), dtype=np.int64)
+    lib = _lib.load()
+    rc = lib.dctfp_stitch_sizes(win_rows.ctypes.data, seq_win.ctypes.data, len(counts), int(overlap), 0, sizes.ctypes.data)
+    _lib.check(rc, lib)
+    return seq_win, sizes
+
+
+def quantize_windows(layers: Sequence[LayerBatch], win_rows, win_counts, table: PieceTable, overlap: int = 200,
+                     out: torch.Tensor = None, ctx: _lib.Context = None, stream=None, fallback: bool = True) -> torch.Tensor:
+    """``Embedding.embed_seq`` + ``Fingerprint.quantize`` without the stitched matrix (``dctfp_quantize_windows``,
+    include/dctfp.h): every ``LayerBatch`` holds one float32 matrix per WINDOW (window w of sequence s at index
+    ``sum(win_counts[:s]) + w``), ``table`` speaks of the stitched sequences (``window_geometry`` gives their rows).  Rows two
+    windows share are averaged in the kernel's row load; the result is what ``stitch_embeddings_batch`` + ``quantize_batch``
+    give, byte for byte.  Calls the one-launch kernel does not take (DCTFP_ERR_UNSUPPORTED: other kept sizes, half-precision
+    rows, a handful of jobs, ...) are stitched first when ``fallback`` is set -- torch allocates the stitched matrices."""
+    if not layers:
+        raise ValueError('no layers')
+    device = layers[0].device
+    total = sum(l.n_keep * l.m_keep for l in layers)
+    if out is None:
+        out = torch.empty((table.n_domains, total), dtype=torch.int8, device=device)
+    elif out.dtype != torch.int8 or out.dim() != 2 or out.shape[0] < table.n_domains or out.shape[1] < total \
+            or out.stride(1) != 1 or out.device != device:
+        raise ValueError('out must be an int8 (n_domains, >= sum n*m) tensor on the layers\' device')
+    if table.n_domains == 0:
+        return out
+    if ctx is None:
+        ctx = _lib.get_context(device.index if device.index is not None else torch.cuda.current_device())
+    win_rows = np.ascontiguousarray(np.asarray(win_rows, dtype=np.int32))
+    seq_win, sizes = window_geometry(win_rows, win_counts, overlap)
+    if len(sizes) != len(table.seq_rows) or (sizes != table.seq_rows).any():
+        raise ValueError('the piece table was not built for the stitched lengths of these windows (window_geometry)')
+    arr = _layer_array(layers, len(win_rows))
+    if stream is None:
+        stream = torch.cuda.current_stream(device)
+    rc = ctx._lib.dctfp_quantize_windows(ctx.handle, arr, len(layers), len(sizes), seq_win.ctypes.data, win_rows.ctypes.data,
+                                         int(overlap), table.pieces.ctypes.data, len(table.pieces), table.n_domains,
+                                         out.data_ptr(), out.stride(0), C.c_void_p(stream.cuda_stream))
+    if rc == _lib.DCTFP_ERR_UNSUPPORTED and fallback:
+        from .embedding import stitch_windows_flat
+        stitched = []
+        for l in layers:
+            big, first = stitch_windows_flat(l, win_rows, seq_win, sizes, overlap)
+            stitched.append(LayerBatch(big, l.n_keep, l.m_keep, row_offsets=first))
+        return quantize_batch(stitched, table, out=out, ctx=ctx, stream=stream)
+    _lib.check(rc, ctx._lib)
+    return out
+
+
 def quantize_batch(layers: Sequence[LayerBatch], table: PieceTable, out: torch.Tensor = None,
                    ctx: _lib.Context = None, stream=None) -> torch.Tensor:
     """Runs ``dctfp_quantize`` (include/dctfp.h) and returns the int8 tensor
@@ -256,19 +332,7 @@ def quantize_batch(layers: Sequence[LayerBatch], table: PieceTable, out: torch.T
     if ctx is None:
         ctx = _lib.get_context(device.index if device.index is not None else torch.cuda.current_device())
     n_seq = len(table.seq_rows)
-    arr = (_lib.Layer * len(layers))()
-    off = 0
-    for i, l in enumerate(layers):
-        if len(l.ptrs) != n_seq:
-            raise ValueError(f'layer {i} has {len(l.ptrs)} sequences, the piece table {n_seq}')
-        arr[i].seq_data = C.cast(C.c_void_p(l.ptrs.ctypes.data), C.POINTER(C.c_void_p))
-        arr[i].ld = l.ld
-        arr[i].n_cols = l.n_cols
-        arr[i].dtype = l.dtype
-        arr[i].n_keep = l.n_keep
-        arr[i].m_keep = l.m_keep
-        arr[i].out_offset = off
-        off += l.n_keep * l.m_keep
+    arr = _layer_array(layers, n_seq)
     if stream is None:
         stream = torch.cuda.current_stream(device)
     rc = ctx._lib.dctfp_quantize(ctx.handle, arr, len(layers), n_seq, table.seq_rows.ctypes.data,

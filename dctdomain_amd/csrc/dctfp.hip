@@ -835,11 +835,65 @@ bool gen_shape(const dctfp_layer& ly) {
     return waves <= 16 && gen_slot_bytes(ly.n_keep, ly.m_keep, waves, vec) + 64 <= kGenLdsBudget;
 }
 
+// Window geometry of one sequence (src/embedding.py:123-150, :185-188): see dctfp_stitch_sizes / dctfp_stitch_sequences.
+// Returns the rows (embeddings) or the side (contact maps) of the stitched result, or -1 where the reference's torch
+// expression would fail to broadcast.  `emit(window, dst_row_offset, n_avg)` is called per window when given.
+template <typename Emit>
+int64_t stitch_geometry(const int32_t* rows, int64_t n_win, int32_t step, bool square, Emit emit) {
+    if (n_win < 1 || rows[0] < 1) return -1;
+    int64_t size = rows[0];
+    emit((int64_t)0, (int64_t)0, (int32_t)0);
+    for (int64_t w = 1; w < n_win; ++w) {
+        if (rows[w] < 1) return -1;
+        if (!square) {      // run[-olp:] = (run[-olp:] + new[:olp]) / 2; cat(new[olp:])
+            if (rows[w] <= step || size < step) return -1;
+            emit(w, size - step, step);
+            size += rows[w] - step;
+        } else {            // combine_contacts: the window lands at offset inc * w, its overlap with the running map is averaged
+            const int64_t off = (int64_t)step * w;
+            if (off > size) return -1;
+            emit(w, off, (int32_t)std::min<int64_t>(size - off, rows[w]));
+            size = off + rows[w];
+        }
+    }
+    return size;
+}
+// The walk kernels address the rows of a piece through a 32-bit buffer offset and stream a whole domain per wave.
+bool walk_rows_ok(const dctfp_ctx* ctx, const dctfp_layer& g, uint32_t max_len_all) {
+    return max_len_all <= kWalkMaxRows && (size_t)g.ld * dtype_size(g.dtype) <= ((size_t)1 << 31) / kWalkMaxRows && ctx->opt_stage_b == 1;
+}
+// ... and take a call by the "path" option: always (2), or from 256 jobs (a smaller call is latency-bound: two kernels)
+bool walk_by_path(const dctfp_ctx* ctx, int64_t n_jobs) { return ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 256); }
+
+// 16 bytes per lane where every row of every sequence (window) allows it.  seq_rows == nullptr: every entry counts.
+bool rows_aligned16(const dctfp_layer* group, int ng, int64_t n_data, const int64_t* seq_rows) {
+    const dctfp_layer& g = group[0];
+    const size_t esz = dtype_size(g.dtype);
+    if (((size_t)g.ld * esz) % 16 != 0 || g.n_cols % (int)(16 / esz) != 0) return false;
+    for (int li = 0; li < ng; ++li)
+        for (int64_t sq = 0; sq < n_data; ++sq)
+            if ((!seq_rows || seq_rows[sq] > 0) && !aligned16(group[li].seq_data[sq])) return false;
+    return true;
+}
+
+// Where the rows of a piece come from when the sequences exist only as the language model's overlapping windows
+// (dctfp_quantize_windows): row r of the piece is row row_a + r of window a -- or, b >= 0, the float32 mean of that row and row
+// row_b + r of window b (the rows two windows share, src/embedding.py:185-187).  seq_data is then indexed by WINDOW.
+struct PieceSrc {
+    int64_t a, row_a;
+    int64_t b, row_b;
+};
+
 // dctfp_quantize proper.  `out_row` (optional): the output row of every domain of THIS piece table (a call that
-// dctfp_quantize has split in two); without it domain d writes row d.  The caller holds the context's mutex.
+// dctfp_quantize has split in two); without it domain d writes row d.  `src` (optional, one per piece; n_data = windows):
+// see PieceSrc -- pieces, seq_rows and seq then speak of the STITCHED sequences.  The caller holds the context's mutex.
 int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, int32_t n_seq, const int64_t* seq_rows,
                   const dctfp_piece* pieces, int64_t n_pieces, int64_t n_domains, int8_t* out, int64_t out_stride,
-                  hipStream_t stream, const int64_t* out_row) {
+                  hipStream_t stream, const int64_t* out_row, const PieceSrc* src = nullptr, int64_t n_data = 0) {
+    if (!src) n_data = n_seq;
+    bool two_source = false;  // some piece is the mean of two windows' rows: only walk_ab_kernel reads those
+    if (src)
+        for (int64_t i = 0; i < n_pieces && !two_source; ++i) two_source = src[i].b >= 0;
 
     // ---- validate the piece table, domain lengths --------------------------------
     std::vector<uint32_t> dom_len((size_t)n_domains, 0), dom_first((size_t)n_domains, 0), dom_np((size_t)n_domains, 0);
@@ -880,8 +934,9 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             return fail(DCTFP_ERR_LIMIT, "layer %d: qdim (%d, %d) above the supported (%d, %d)", l, ly.n_keep, ly.m_keep, DCTFP_MAX_N, DCTFP_MAX_M);
         if (ly.out_offset < 0 || (int64_t)ly.out_offset + (int64_t)ly.n_keep * ly.m_keep > out_stride)
             return fail(DCTFP_ERR_INVALID, "layer %d: block [%d, +%d) outside out_stride %lld", l, ly.out_offset, ly.n_keep * ly.m_keep, (long long)out_stride);
-        for (int32_t s = 0; s < n_seq; ++s)
-            if (!ly.seq_data[s] && seq_rows[s] > 0) return fail(DCTFP_ERR_INVALID, "layer %d: sequence %d has no data", l, s);
+        for (int64_t s = 0; s < n_data; ++s)
+            if (!ly.seq_data[s] && (src || seq_rows[s] > 0))
+                return fail(DCTFP_ERR_INVALID, src ? "layer %d: window %lld has no data" : "layer %d: sequence %lld has no data", l, (long long)s);
         // the reference's reshape failure (src/fingerprint.py:194): L_d < n or D < m
         if ((int64_t)min_len < ly.n_keep) {
             for (int64_t d = 0; d < n_domains; ++d)
@@ -918,6 +973,15 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             if (ok) {
                 const dctfp_piece& w = pieces[dom_first[e]];
                 ok = dom_np[e] == 1 && w.row_start == 0 && w.n_rows == seq_rows[s0];
+                if (src && !ok) {  // the whole protein of a windowed sequence: one piece per window region, back to back
+                    int64_t pos = 0;
+                    ok = true;
+                    for (uint32_t k = 0; k < dom_np[e] && ok; ++k) {
+                        ok = pieces[dom_first[e] + k].row_start == pos;
+                        pos += pieces[dom_first[e] + k].n_rows;
+                    }
+                    ok = ok && pos == seq_rows[s0];
+                }
             }
             if (ok) {
                 runs.clear();
@@ -1004,20 +1068,18 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
 
         const int ldy_pre = (int)align_up((size_t)g.n_cols, 32);
         // 16 bytes per lane where every row of every sequence allows it
-        bool vec_ok = true;
-        for (int li = 0; li < ng && vec_ok; ++li)
-            for (int32_t sq = 0; sq < n_seq && vec_ok; ++sq)
-                if (seq_rows[sq] > 0 && !aligned16(layers[l0 + li].seq_data[sq])) vec_ok = false;
+        const bool vec_ok = rows_aligned16(layers + l0, ng, n_data, src ? nullptr : seq_rows);
         const int vec_want = (int)(16 / esz);  // 16 bytes per lane
-        if (((size_t)g.ld * esz) % 16 != 0 || g.n_cols % vec_want != 0) vec_ok = false;
         // ---- which kernels.  The walk kernel (stage A + B in one launch, nothing but int8 written) takes the production
         // shapes: n = 3, 64 < m <= 80 (five 16-column groups), rows read 4 channels per lane, 512 <= D <= 2560, no giant domain
         // (a wave streams all rows of its channels).  Every other shape of float32 / float64 rows that fits the LDS goes to the
         // general walk kernel (round 4); the rest -- and calls too small to fill the chip -- run stage A -> Y' -> stage B.
         // (rows are addressed through a 32-bit buffer offset: a piece of at most kWalkMaxRows rows stays below 2^31 bytes)
-        const bool rows_ok = max_len_all <= kWalkMaxRows && (size_t)g.ld * esz <= ((size_t)1 << 31) / kWalkMaxRows && ctx->opt_stage_b == 1;
+        const bool rows_ok = walk_rows_ok(ctx, g, max_len_all);
         const bool walk_ok = !trivial && walk_shape(g) && vec_ok && rows_ok;
-        const bool use_walk = walk_ok && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 256));
+        const bool use_walk = walk_ok && walk_by_path(ctx, n_jobs);
+        if (two_source && !(use_walk && g.dtype == DCTFP_F32))  // (dctfp_quantize_windows has asked takes_two_sources() before anything was launched)
+            return fail(DCTFP_ERR_UNSUPPORTED, "internal: two-source pieces outside the walk kernel");
         int gen_vec = 0, gen_waves = 0, gen_slots = 0;
         if (!trivial && !walk_ok && rows_ok && n >= 2 && m >= 2 && (g.dtype == DCTFP_F32 || g.dtype == DCTFP_F64)) {
             gen_vec = vec_ok ? vec_want : 1;
@@ -1059,7 +1121,8 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
                 if (fuse && grp_end[d] >= 0 && !is_whole[d]) {
                     const int64_t w = grp_end[d];  // the whole-protein domain closes the group
                     hja[job].w_basis = dom_tab[w];
-                    hja[job].w_ref = ly.seq_data[pieces[dom_first[w]].seq];
+                    // (windows: row 0 of a sequence is row 0 of its first window -- a window is longer than the overlap)
+                    hja[job].w_ref = src ? ly.seq_data[src[dom_first[w]].a] : ly.seq_data[pieces[dom_first[w]].seq];
                 }
             }
             uint32_t t0 = 0;
@@ -1069,7 +1132,14 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
                 if (pc.domain != prev_dom) t0 = 0;
                 prev_dom = pc.domain;
                 PieceA& o = hpc[(int64_t)li * n_pieces + i];
-                o.ptr = (const char*)ly.seq_data[pc.seq] + (size_t)pc.row_start * (size_t)ly.ld * esz;
+                if (src) {
+                    const PieceSrc& ps = src[i];
+                    o.ptr = (const char*)ly.seq_data[ps.a] + (size_t)ps.row_a * (size_t)ly.ld * esz;
+                    o.ptr2 = ps.b >= 0 ? (const char*)ly.seq_data[ps.b] + (size_t)ps.row_b * (size_t)ly.ld * esz : nullptr;
+                } else {
+                    o.ptr = (const char*)ly.seq_data[pc.seq] + (size_t)pc.row_start * (size_t)ly.ld * esz;
+                    o.ptr2 = nullptr;
+                }
                 o.n_rows = (uint32_t)pc.n_rows;
                 o.t0 = t0;
                 o.w0 = (uint32_t)pc.row_start;
@@ -1097,7 +1167,7 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             wg_per_cu = use_gen ? std::max<int64_t>(1, std::min<int64_t>(20 / gen_waves, (int64_t)(kGenLdsBudget / (gen_slots * gen_slot_bytes(n, m, gen_waves, gen_vec) + 64))))
                                 : (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));
             // jobs per flush: 4 = the rows of an MFMA tile (a flush costs the same MFMAs for 1..4 jobs)
-            walk_g = ctx->opt_ab_group ? (int)ctx->opt_ab_group : 4;
+            walk_g = ctx->opt_ab_group && !two_source ? (int)ctx->opt_ab_group : 4;
             for (int64_t j = 0; j < n_jobs;) {
                 const int64_t d = j % n_domains;
                 Walk& wk = hwalk[n_walks++];
@@ -1429,9 +1499,11 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             wp.degenerate = ctx->degenerate;
             wp.grid = (unsigned)n_runs;
             wp.stream = stream;
+            wp.two_source = two_source;
             {
                 LaunchError le;
-                rc = launcher_rc(launch_walk(wp, g.dtype, walk_s, walk_g, ctx->opt_ab_unroll ? (int)ctx->opt_ab_unroll : 8, fuse, ctx->opt_ab_mfma_a != 0, &le), le);
+                rc = launcher_rc(launch_walk(wp, g.dtype, walk_s, walk_g, ctx->opt_ab_unroll && !two_source ? (int)ctx->opt_ab_unroll : 8, fuse,
+                                             ctx->opt_ab_mfma_a != 0 && !two_source, &le), le);
             }
             if (rc) return rc;
             HIP_TRY(hipGetLastError());
@@ -1641,6 +1713,114 @@ int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, 
     }
     return quantize_impl(ctx, layers, n_layers, n_seq, seq_rows, pieces, n_pieces, n_domains, out, out_stride, stream, nullptr);
 } DCTFP_GUARD("dctfp_quantize")
+
+int dctfp_quantize_windows(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, int32_t n_seq, const int64_t* seq_win,
+                           const int32_t* win_rows, int32_t overlap, const dctfp_piece* pieces, int64_t n_pieces,
+                           int64_t n_domains, int8_t* out, int64_t out_stride, void* stream_v) try {
+    if (!ctx) return fail(DCTFP_ERR_INVALID, "dctfp_quantize_windows: ctx is NULL");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_layers < 0 || n_seq < 0 || n_pieces < 0 || n_domains < 0 || overlap < 0)
+        return fail(DCTFP_ERR_INVALID, "dctfp_quantize_windows: negative count");
+    if (n_layers == 0 || n_domains == 0) return DCTFP_OK;
+    if (!layers || !seq_win || !win_rows || !pieces || !out) return fail(DCTFP_ERR_INVALID, "dctfp_quantize_windows: NULL argument");
+    if (n_pieces >= (int64_t)1 << 30 || n_domains >= (int64_t)1 << 31)
+        return fail(DCTFP_ERR_LIMIT, "dctfp_quantize_windows: too many pieces or domains in one call");
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    // ---- where every window lands in its stitched sequence (the geometry of dctfp_stitch_sequences)
+    if (seq_win[0] != 0) return fail(DCTFP_ERR_INVALID, "dctfp_quantize_windows: seq_win[0] must be 0");
+    for (int32_t s = 0; s < n_seq; ++s)
+        if (seq_win[s + 1] < seq_win[s]) return fail(DCTFP_ERR_INVALID, "dctfp_quantize_windows: seq_win must not decrease");
+    const int64_t n_win = seq_win[n_seq];
+    std::vector<int64_t> seq_rows((size_t)n_seq), win_off((size_t)n_win);
+    bool simple = true;  // every row is one window's row or the mean of two
+    for (int32_t s = 0; s < n_seq; ++s) {
+        const int64_t w0 = seq_win[s], n = seq_win[s + 1] - w0;
+        const int64_t size = n > 0 ? stitch_geometry(win_rows + w0, n, overlap, false, [&](int64_t w, int64_t off, int32_t) { win_off[(size_t)(w0 + w)] = off; }) : 0;
+        if (size < 0) return fail(DCTFP_ERR_SHAPE, "sequence %d: a window is not longer than the overlap", s);
+        seq_rows[(size_t)s] = size;
+        for (int64_t w = w0 + 1; w + 1 < w0 + n; ++w)
+            if (win_rows[w] < 2 * (int64_t)overlap) simple = false;
+    }
+    if (!simple)
+        return fail(DCTFP_ERR_UNSUPPORTED, "dctfp_quantize_windows: three windows meet in one row (a window between two others has fewer than "
+                                           "2 x %d rows): stitch with dctfp_stitch_sequences, then dctfp_quantize", overlap);
+
+    // ---- the caller's pieces (stitched rows) cut at the region borders: a run of one window's own rows, or of rows two share
+    std::vector<dctfp_piece> sub;
+    std::vector<PieceSrc> src;
+    sub.reserve((size_t)n_pieces + (size_t)n_pieces / 2);
+    src.reserve((size_t)n_pieces + (size_t)n_pieces / 2);
+    bool two_source = false;
+    for (int64_t i = 0; i < n_pieces; ++i) {
+        const dctfp_piece& pc = pieces[i];
+        if (pc.seq < 0 || pc.seq >= n_seq) return fail(DCTFP_ERR_INVALID, "piece %lld: sequence %d out of range", (long long)i, pc.seq);
+        if (pc.n_rows <= 0 || pc.row_start < 0 || pc.row_start + pc.n_rows > seq_rows[(size_t)pc.seq])
+            return fail(DCTFP_ERR_INVALID, "piece %lld: rows [%lld, +%d) outside sequence %d of %lld stitched rows", (long long)i,
+                        (long long)pc.row_start, pc.n_rows, pc.seq, (long long)seq_rows[(size_t)pc.seq]);
+        const int64_t w0 = seq_win[pc.seq], n = seq_win[pc.seq + 1] - w0;
+        const int64_t* off = win_off.data() + w0;
+        // window w owns the stitched rows [off[w], off[w + 1]): its first `overlap` rows (w > 0) shared with w - 1, the rest its own
+        int64_t w = std::upper_bound(off, off + n, pc.row_start) - off - 1;
+        int64_t pos = pc.row_start, left = pc.n_rows;
+        while (left > 0) {
+            while (w + 1 < n && off[w + 1] <= pos) ++w;
+            const int64_t local = pos - off[w];
+            dctfp_piece sp = pc;
+            PieceSrc ps;
+            int64_t take;
+            if (w > 0 && local < overlap) {  // (old + new) / 2: old = the predecessor's tail, new = this window's head
+                take = std::min<int64_t>(left, overlap - local);
+                ps.a = w0 + w - 1;
+                ps.row_a = win_rows[w0 + w - 1] - overlap + local;
+                ps.b = w0 + w;
+                ps.row_b = local;
+                two_source = true;
+            } else {
+                const int64_t own_end = win_rows[w0 + w] - (w + 1 < n ? overlap : 0);
+                take = std::min<int64_t>(left, own_end - local);
+                ps.a = w0 + w;
+                ps.row_a = local;
+                ps.b = -1;
+                ps.row_b = 0;
+            }
+            if (take <= 0) return fail(DCTFP_ERR_INVALID, "internal: window geometry of sequence %d", pc.seq);
+            sp.row_start = pos;
+            sp.n_rows = (int32_t)take;
+            sub.push_back(sp);
+            src.push_back(ps);
+            pos += take;
+            left -= take;
+        }
+    }
+
+    // ---- only walk_ab_kernel averages two windows in its row load: a call it would not get is refused before anything runs
+    if (two_source) {
+        std::vector<uint32_t> len((size_t)n_domains, 0);
+        uint32_t max_len = 0;
+        for (const dctfp_piece& pc : sub)
+            if (pc.domain >= 0 && pc.domain < n_domains) max_len = std::max(max_len, len[(size_t)pc.domain] += (uint32_t)pc.n_rows);
+        for (int32_t l0 = 0; l0 < n_layers;) {
+            const dctfp_layer& g = layers[l0];
+            int32_t l1 = l0 + 1;
+            while (l1 < n_layers && layers[l1].n_cols == g.n_cols && layers[l1].dtype == g.dtype && layers[l1].ld == g.ld &&
+                   layers[l1].n_keep == g.n_keep && layers[l1].m_keep == g.m_keep)
+                ++l1;
+            const char* why = nullptr;
+            if (!g.seq_data || g.dtype != DCTFP_F32) why = "windows are averaged in float32 (as dctfp_stitch)";
+            else if (!walk_shape(g)) why = "kept sizes / width outside the one-launch kernel's (n = 3, 64 < m <= 80, 512 <= D <= 2560, D % 4 == 0)";
+            else if (!rows_aligned16(layers + l0, l1 - l0, n_win, nullptr)) why = "rows are not 16-byte aligned";
+            else if (!walk_rows_ok(ctx, g, max_len)) why = "a domain above 8 192 rows";
+            else if (!walk_by_path(ctx, (int64_t)(l1 - l0) * n_domains)) why = "fewer than 256 jobs (layers x domains) in the call";
+            if (why)
+                return fail(DCTFP_ERR_UNSUPPORTED, "dctfp_quantize_windows: layer %d: %s -- stitch with dctfp_stitch_sequences, then dctfp_quantize", l0, why);
+            l0 = l1;
+        }
+    }
+    return quantize_impl(ctx, layers, n_layers, n_seq, seq_rows.data(), sub.data(), (int64_t)sub.size(), n_domains, out, out_stride, stream,
+                         nullptr, src.data(), n_win);
+} DCTFP_GUARD("dctfp_quantize_windows")
 
 int dctfp_idct_quant(dctfp_ctx* ctx, const void* vec, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
                      int32_t num, double* scaled_out, double* coef_out, void* stream_v) try {
@@ -2003,29 +2183,6 @@ int stitch_impl(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, in
     return mark_table_used(ctx, buf, stream);
 }
 
-// Window geometry of one sequence (src/embedding.py:123-150, :185-188): see dctfp_stitch_sizes / dctfp_stitch_sequences.
-// Returns the rows (embeddings) or the side (contact maps) of the stitched result, or -1 where the reference's torch
-// expression would fail to broadcast.  `emit(window, dst_row_offset, n_avg)` is called per window when given.
-template <typename Emit>
-int64_t stitch_geometry(const int32_t* rows, int64_t n_win, int32_t step, bool square, Emit emit) {
-    if (n_win < 1 || rows[0] < 1) return -1;
-    int64_t size = rows[0];
-    emit((int64_t)0, (int64_t)0, (int32_t)0);
-    for (int64_t w = 1; w < n_win; ++w) {
-        if (rows[w] < 1) return -1;
-        if (!square) {      // run[-olp:] = (run[-olp:] + new[:olp]) / 2; cat(new[olp:])
-            if (rows[w] <= step || size < step) return -1;
-            emit(w, size - step, step);
-            size += rows[w] - step;
-        } else {            // combine_contacts: the window lands at offset inc * w, its overlap with the running map is averaged
-            const int64_t off = (int64_t)step * w;
-            if (off > size) return -1;
-            emit(w, off, (int32_t)std::min<int64_t>(size - off, rows[w]));
-            size = off + rows[w];
-        }
-    }
-    return size;
-}
 }  // namespace
 
 extern "C" {

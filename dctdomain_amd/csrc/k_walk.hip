@@ -18,6 +18,17 @@ void launch_walk_impl(const WParams& p, bool fused, bool mfma_a = false) {
 #else
     (void)mfma_a;
 #endif
+    if constexpr (sizeof(T) == 4 && UNROLL == 8 && G == 4) {
+        if (p.two_source) {  // pieces that are the mean of two windows' rows (dctfp_quantize_windows): builds of their own
+            if (fused)
+                hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true, false, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb,
+                                   p.walks, p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
+            else
+                hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, false, false, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb,
+                                   p.walks, p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
+            return;
+        }
+    }
     if (fused)
         hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb, p.walks,
                            p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);

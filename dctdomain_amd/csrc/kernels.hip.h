@@ -54,6 +54,11 @@ struct PieceA {
     uint32_t t0;      // position of the piece's first row inside the domain matrix
     uint32_t w0;      // position of the piece's first row inside the whole protein
     uint32_t reserved;
+    // Rows that exist only as the overlap of two WINDOWS of the language model (Embedding.embed_seq, src/embedding.py:185-187:
+    // run[-olp:] = (run[-olp:] + new[:olp]) / 2): row r of the piece is the float32 (ptr row r + ptr2 row r) / 2, taken in the
+    // row load of walk_ab_kernel -- the stitched matrix is never written (dctfp_quantize_windows).  nullptr: an ordinary piece.
+    // Only walk_ab_kernel (float32 rows) reads it; the host sends two-source pieces nowhere else.
+    const void* ptr2;
 };
 
 struct JobB {
@@ -1024,6 +1029,14 @@ __device__ inline void lane_rows_transpose(const double (&r)[4], double (&o)[NOU
     for (int i = 0; i < NOUT; ++i) o[i] = __hiloint2double((int)w[i][1], (int)w[i][0]);
 }
 
+// The row two overlapping windows share, as Embedding.embed_seq leaves it (src/embedding.py:185-187): float32 (old + new) / 2 --
+// the sum rounded to float32, the halving exact -- the very expression of stitch_rows_kernel.
+template <typename R>
+__device__ inline R window_mean(const R& a, const R& b) {
+    static_assert(std::is_same<R, v4f>::value, "windows are stitched in float32 (as dctfp_stitch)");
+    return (R){(a[0] + b[0]) / 2.0f, (a[1] + b[1]) / 2.0f, (a[2] + b[2]) / 2.0f, (a[3] + b[3]) / 2.0f};
+}
+
 struct Run {
     uint32_t walk_begin;  // first Walk of this workgroup
     uint32_t n_walks;
@@ -1066,7 +1079,9 @@ struct Run {
 #define DCTFP_TL_ANCHOR(x)
 #endif
 
-template <typename T, int S, int G, int NT, int UNROLL, bool FUSED, bool MA = false>
+// WIN: builds that also take two-source pieces (PieceA::ptr2; float32 rows) -- builds of their own, because the fused variants sit
+// exactly at their register budget and the second row stream costs the ordinary calls nothing this way.
+template <typename T, int S, int G, int NT, int UNROLL, bool FUSED, bool MA = false, bool WIN = false>
 __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void walk_ab_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
                                                           const Walk* __restrict__ walks, const Run* __restrict__ runs,
                                                           const PieceA* __restrict__ pieces, const double* __restrict__ stf,
@@ -1288,7 +1303,11 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 // D = 640 database-build mix, tools/clock_probe.py), and a masked lane does not pay for 24 float64 operations per row.
                 if (!pad) {
                 {
-                    const Rw r0 = load_raw<T, VEC>(reinterpret_cast<const T*>(pc[0].ptr) + colc);
+                    Rw r0 = load_raw<T, VEC>(reinterpret_cast<const T*>(pc[0].ptr) + colc);
+                    if constexpr (WIN) {  // a job that starts inside the overlap of two windows: its first row is their mean
+                        const T* __restrict__ p2 = reinterpret_cast<const T*>(pc[0].ptr2);
+                        if (p2) r0 = window_mean(load_raw<T, VEC>(p2 + colc), r0);
+                    }
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) ref[v] = raw_elem<T, VEC>(r0, v);
                 }
@@ -1303,8 +1322,9 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 // the row stream made the variant 3 % slower at D <= 1280 although it issues 9 % fewer instructions -- PMC:
                 // profiles/r02/pmc_single_shift_*.md).  An exactly constant channel still gives exactly 0: both terms vanish.
                 double cwsum[NK] = {0.0, 0.0};
-                auto stream_piece = [&](auto hw_tag, const PieceA& piece) {
+                auto stream_piece = [&](auto hw_tag, auto two_tag, const PieceA& piece) {
                     constexpr bool HW = decltype(hw_tag)::value;
+                    constexpr bool TWO = decltype(two_tag)::value;  // rows = the float32 mean of two windows' rows (PieceA::ptr2)
                     const __amdgpu_buffer_rsrc_t rows = wave_buffer(piece.ptr);
                     auto load_row = [&](uint32_t r) { return buffer_load_raw<Rw, true>(rows, col_bytes, (int)r * ld_bytes); };
                     const CosTab btp = cos_tab(job.basis) + (size_t)piece.t0 * NK;
@@ -1324,6 +1344,36 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                         }
                     };
                     uint32_t r = 0;
+                    if constexpr (TWO) {
+                        // UNROLL / 2 row PAIRS in flight (the same bytes as UNROLL rows), each pair reduced to its float32 mean --
+                        // (old + new) / 2 as the reference's torch expression and stitch_rows_kernel do it -- before the promotion
+                        // to float64: per KiB read, half the float64 work of an ordinary piece.
+                        const __amdgpu_buffer_rsrc_t rows2 = wave_buffer(piece.ptr2);
+                        auto load_row2 = [&](uint32_t rr) { return buffer_load_raw<Rw, true>(rows2, col_bytes, (int)rr * ld_bytes); };
+                        constexpr int PAIRS = HW ? UNROLL / 4 : UNROLL / 2;  // (the fused variants have no registers to spare)
+                        for (; r + PAIRS <= piece.n_rows; r += PAIRS) {
+                            Rw xa[PAIRS], xb[PAIRS];
+#pragma unroll
+                            for (int u = 0; u < PAIRS; ++u) {
+                                xa[u] = load_row(r + u);
+                                xb[u] = load_row2(r + u);
+                            }
+#pragma unroll
+                            for (int u = 0; u < PAIRS; ++u) row_update(window_mean(xa[u], xb[u]), r + u);
+                        }
+                        if (r < piece.n_rows) {  // the last 1 .. PAIRS - 1 pairs, their loads issued together
+                            Rw xa[PAIRS - 1], xb[PAIRS - 1];
+#pragma unroll
+                            for (int u = 0; u < PAIRS - 1; ++u)
+                                if (r + u < piece.n_rows) {
+                                    xa[u] = load_row(r + u);
+                                    xb[u] = load_row2(r + u);
+                                }
+#pragma unroll
+                            for (int u = 0; u < PAIRS - 1; ++u)
+                                if (r + u < piece.n_rows) row_update(window_mean(xa[u], xb[u]), r + u);
+                        }
+                    } else {
                     for (; r + UNROLL <= piece.n_rows; r += UNROLL) {
                         Rw xv[UNROLL];
 #pragma unroll
@@ -1351,6 +1401,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                         for (int u = 0; u < 3; ++u)
                             if (r + u < piece.n_rows) row_update(xv[u], r + u);
                     }
+                    }  // !TWO
                     if constexpr (HW) {  // prefix sums past this piece's last and at its first row
                         const CosTab wpre = wtp + (size_t)w_rows * NK;
 #pragma unroll
@@ -1359,8 +1410,15 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 };
                 for (uint32_t p = 0; p < job.n_pieces; ++p) {
                     const PieceA piece = pc[p];
-                    if (FUSED && has_w) stream_piece(std::integral_constant<bool, FUSED>{}, piece);
-                    else stream_piece(std::false_type{}, piece);
+                    if constexpr (WIN) {
+                        if (piece.ptr2) {
+                            if (FUSED && has_w) stream_piece(std::integral_constant<bool, FUSED>{}, std::true_type{}, piece);
+                            else stream_piece(std::false_type{}, std::true_type{}, piece);
+                            continue;
+                        }
+                    }
+                    if (FUSED && has_w) stream_piece(std::integral_constant<bool, FUSED>{}, std::false_type{}, piece);
+                    else stream_piece(std::false_type{}, std::false_type{}, piece);
                 }
                 if (FUSED && has_w) {
                     const Rw w0 = load_raw<T, VEC>(reinterpret_cast<const T*>(job.w_ref) + colc);

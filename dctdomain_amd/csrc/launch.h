@@ -87,6 +87,7 @@ struct WParams {
     unsigned long long* degenerate;
     unsigned grid;
     hipStream_t stream;
+    bool two_source = false;  // some piece has PieceA::ptr2 (float32 rows, 8 rows in flight, 4 jobs per flush only)
 };
 
 // walk_gen_kernel: the shapes walk_ab_kernel does not take.

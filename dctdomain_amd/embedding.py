@@ -204,6 +204,29 @@ def _stitch_sequences(flat, counts, step: int, square: bool, n_cols: int):
     return _Views(big, first, sizes, square)
 
 
+def stitch_windows_flat(layer, win_rows, seq_win, sizes, overlap: int = OVERLAP):
+    """The stitched matrices of ONE layer given as a ``batch.LayerBatch`` of float32 windows (device pointers + common row
+    stride): (one (sum sizes, D) tensor, first row of every sequence).  What ``batch.quantize_windows`` falls back to when a call
+    is not one the window-averaging kernel takes."""
+    if layer.dtype != _lib.DCTFP_F32:
+        raise ValueError('windows are stitched in float32, as the reference does (src/embedding.py:185-187)')
+    n_seq, n_win = len(sizes), len(win_rows)
+    big = torch.empty((int(sizes.sum()), layer.n_cols), dtype=torch.float32, device=layer.device)
+    first = np.zeros(n_seq, dtype=np.int64)
+    np.cumsum(sizes[:-1], out=first[1:])
+    dst = np.uint64(big.data_ptr()) + first.astype(np.uint64) * np.uint64(4 * layer.n_cols)
+    lds = np.full(n_win, layer.ld, dtype=np.int64)
+    dst_ld = np.full(n_seq, layer.n_cols, dtype=np.int64)
+    lib = _lib.load()
+    ctx = _lib.get_context(layer.device.index)
+    stream = torch.cuda.current_stream(layer.device)
+    _lib.check(lib.dctfp_stitch_sequences(ctx.handle, layer.ptrs.ctypes.data, np.ascontiguousarray(win_rows, dtype=np.int32).ctypes.data,
+                                          lds.ctypes.data, np.ascontiguousarray(seq_win, dtype=np.int64).ctypes.data, n_seq,
+                                          dst.ctypes.data, dst_ld.ctypes.data, int(layer.n_cols), int(overlap), 0,
+                                          C.c_void_p(stream.cuda_stream)), lib)
+    return big, first
+
+
 def stitch_embeddings_batch(seq_windows: List[List[torch.Tensor]], overlap: int = OVERLAP):
     """Same for many sequences: one kernel launch per window index for the whole batch.  The window geometry is worked
     out in C (``dctfp_stitch_sequences``); the results come back as a sequence of views of ONE allocation (keep one and

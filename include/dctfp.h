@@ -43,6 +43,9 @@ extern "C" {
 #define DCTFP_ERR_HIP (-3)     /* a HIP runtime call failed */
 #define DCTFP_ERR_NOMEM (-4)   /* workspace allocation failed */
 #define DCTFP_ERR_LIMIT (-5)   /* n > DCTFP_MAX_N or m > DCTFP_MAX_M */
+#define DCTFP_ERR_UNSUPPORTED (-6) /* dctfp_quantize_windows only: the call is valid but the one-launch kernel that averages two
+                                      windows in its row load does not take it; nothing was launched -- materialise the stitched
+                                      matrices (dctfp_stitch_sequences) and call dctfp_quantize */
 
 #define DCTFP_MAX_N 8   /* kept points along the sequence axis (reference: 3; PROST: 5) */
 #define DCTFP_MAX_M 128 /* kept points along the channel axis  (reference: 80; PROST: 44/85) */
@@ -118,6 +121,24 @@ int dctfp_destroy(dctfp_ctx* ctx);
 int dctfp_quantize(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, int32_t n_seq,
                    const int64_t* seq_rows, const dctfp_piece* pieces, int64_t n_pieces,
                    int64_t n_domains, int8_t* out, int64_t out_stride, void* stream);
+
+/* The same over sequences that exist only as the overlapping WINDOWS the language model embedded -- Embedding.embed_seq
+ * (src/embedding.py:153-192) followed by Fingerprint.quantize (src/fingerprint.py:174-201) with the stitched matrix
+ *     run[-olp:] = (run[-olp:] + new[:olp]) / 2;  run = cat(run, new[olp:])          (src/embedding.py:185-187)
+ * never written: a row two windows share is averaged -- float32 (old + new) / 2, bit for bit what dctfp_stitch_sequences writes --
+ * in the row load of the kernel that streams it, so every window row is read once and nothing but the int8 result reaches HBM
+ * (stitch, then quantize: the windows read + the stitched matrix written + read again).
+ *   layers[l].seq_data : HOST array [seq_win[n_seq]] of DEVICE pointers, one per WINDOW (float32), window w of sequence s at
+ *                        index seq_win[s] + w;  seq_win, win_rows, overlap as in dctfp_stitch_sequences (square = 0)
+ *   pieces             : rows in STITCHED coordinates (dctfp_stitch_sizes gives each sequence's rows)
+ * Results are identical to dctfp_stitch_sequences + dctfp_quantize.  Errors: DCTFP_ERR_SHAPE where the reference's torch expression
+ * would fail to broadcast (a window not longer than the overlap) or a domain is shorter than n; DCTFP_ERR_UNSUPPORTED when
+ * some row is shared and the call is not one the one-launch kernel takes (see "path": float32 rows 16-byte aligned, n = 3,
+ * 64 < m <= 80, 512 <= D <= 2560, 256 jobs or "path" = 2, no domain above 8 192 rows, every window between two others at least
+ * 2 x overlap rows) -- nothing has been launched then.  Sequences of one window each are taken in every shape. */
+int dctfp_quantize_windows(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, int32_t n_seq, const int64_t* seq_win,
+                           const int32_t* win_rows, int32_t overlap, const dctfp_piece* pieces, int64_t n_pieces,
+                           int64_t n_domains, int8_t* out, int64_t out_stride, void* stream);
 
 /* Fingerprint.idct_quant(vec, num) for a (n_rows, n_cols) device matrix
  * (src/fingerprint.py:126-142): DCT-II (ortho) along the rows, keep `num`, inverse DCT of

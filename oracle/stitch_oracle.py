@@ -30,6 +30,16 @@ def combine_contacts(mat1, mat2, inc, times):
     return new
 
 
+def stitch_embeddings(windows, olp=200):
+    """One layer: ``run[-olp:] = (run[-olp:] + new[:olp]) / 2; run = cat(run, new[olp:])`` over the windows (:185-187),
+    torch-CPU float32 as in the reference."""
+    run = windows[0].clone()
+    for emb in windows[1:]:
+        run[-olp:] = (run[-olp:] + emb[:olp]) / 2
+        run = torch.cat((run, emb[olp:]), axis=0)
+    return run
+
+
 def stitch(window_embeds, window_contacts, maxlen, olp=200):
     """window_embeds: list (per window) of {layer: (W, D) float32}; window_contacts: list of (W, W)."""
     edata = None

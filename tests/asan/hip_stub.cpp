@@ -25,6 +25,7 @@ struct JobA {
 struct PieceA {
     const void* ptr;
     uint32_t n_rows, t0, w0, reserved;
+    const void* ptr2;
 };
 struct JobB {
     int64_t out_off;
@@ -41,7 +42,7 @@ struct BasisJob {
     double* tab;
     uint32_t len, reserved;
 };
-static_assert(sizeof(JobA) == 40 && sizeof(PieceA) == 24 && sizeof(JobB) == 8 && sizeof(Walk) == 16 && sizeof(Run) == 16 && sizeof(BasisJob) == 16,
+static_assert(sizeof(JobA) == 40 && sizeof(PieceA) == 32 && sizeof(JobB) == 8 && sizeof(Walk) == 16 && sizeof(Run) == 16 && sizeof(BasisJob) == 16,
               "job-table records as in kernels.hip.h");
 
 namespace {
@@ -118,6 +119,11 @@ void emulate_walk(const std::string& name, dim3 grid, void** a) {
                         if (pc.n_rows == 0 || pc.t0 != rows) { fprintf(stderr, "stub: piece table of job %u broken\n", job_id); abort(); }
                         touch(pc.ptr, (size_t)n_cols * esz);
                         touch((const char*)pc.ptr + (size_t)(pc.n_rows - 1) * (size_t)ld * esz, (size_t)n_cols * esz);
+                        if (pc.ptr2) {  // the mean of two windows' rows: only the builds with the last template flag set read it
+                            if (name.find("Lb1EEEvPK") == std::string::npos || esz != 4) { fprintf(stderr, "stub: two-source piece sent to %s\n", name.c_str()); abort(); }
+                            touch(pc.ptr2, (size_t)n_cols * esz);
+                            touch((const char*)pc.ptr2 + (size_t)(pc.n_rows - 1) * (size_t)ld * esz, (size_t)n_cols * esz);
+                        }
                         touch(job.basis + (size_t)pc.t0 * 2, (size_t)pc.n_rows * 2 * sizeof(double));
                         // the compiler merges the cosines of up to four rows into one scalar load: 8 doubles from any row
                         touch(job.basis + (size_t)(pc.t0 + pc.n_rows - 1) * 2, 8 * sizeof(double));
@@ -164,6 +170,7 @@ void emulate_stage_a(const std::string& name, dim3 grid, void** a) {
             const JobA job = jobs[wk.job_begin + part];
             for (uint32_t p = 0; p < job.n_pieces; ++p) {
                 const PieceA pc = pieces[job.piece_begin + p];
+                if (pc.ptr2) { fprintf(stderr, "stub: two-source piece sent to %s\n", name.c_str()); abort(); }
                 touch(pc.ptr, (size_t)n_cols * esz);
                 touch((const char*)pc.ptr + (size_t)(pc.n_rows - 1) * (size_t)ld * esz, (size_t)n_cols * esz);
                 touch(job.basis + (size_t)pc.t0 * nk, (size_t)pc.n_rows * nk * sizeof(double));
@@ -210,6 +217,7 @@ void emulate_walk_gen(const std::string& name, dim3 grid, dim3 block, size_t shm
             for (uint32_t p = 0; p < job.n_pieces; ++p) {
                 const PieceA pc = pieces[job.piece_begin + p];
                 if (pc.n_rows == 0 || pc.t0 != rows) { fprintf(stderr, "stub: piece table of job %u broken\n", run.job_begin + j); abort(); }
+                if (pc.ptr2) { fprintf(stderr, "stub: two-source piece sent to %s\n", name.c_str()); abort(); }
                 touch(pc.ptr, (size_t)n_cols * esz);
                 touch((const char*)pc.ptr + (size_t)(pc.n_rows - 1) * (size_t)ld * esz, (size_t)n_cols * esz);
                 touch(job.basis + (size_t)pc.t0 * (n - 1), (size_t)pc.n_rows * (n - 1) * sizeof(double));
