@@ -397,12 +397,12 @@ def measure(args, wl, steps, warmup, env):
                 traffic = entry['hbm_bytes_per_launch']
                 traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {tj.get('measured', '')}: 2 x FETCH_SIZE KiB + WRITE_SIZE KiB"
         extra = ''
-        if wl == 'c3':
-            extra = {'fused': f'; given as {len(win_rows)} windows (maxlen {MAXLEN}, overlap {OVERLAP}: {data_rows} window rows), the rows two '
-                              f'windows share averaged in the row load (dctfp_quantize_windows), nothing but int8 written',
-                     'stitch': f'; given as {len(win_rows)} windows (maxlen {MAXLEN}, overlap {OVERLAP}: {data_rows} window rows), stitched into '
-                               f'HBM (dctfp_stitch_sequences) and fingerprinted (dctfp_quantize) in every step',
-                     'stitched': '; ALREADY STITCHED matrices (not BASELINE config 3 as stated)'}[args.c3_form] if wl == 'c3' else ''
+        if wl == 'c3' and not windows:
+            extra = '; ALREADY STITCHED matrices (not BASELINE config 3 as stated)'
+        elif wl == 'c3':
+            extra = f'; given as {len(win_rows)} windows (maxlen {MAXLEN}, overlap {OVERLAP}: {data_rows} window rows), ' + (
+                'the rows two windows share averaged in the row load (dctfp_quantize_windows), nothing but int8 written' if args.c3_form == 'fused'
+                else 'stitched into HBM (dctfp_stitch_sequences) and fingerprinted (dctfp_quantize) in every step')
         res = {
             'value': value, 'ms_per_step': 1e3 * elapsed / steps, 'steps': steps, 'warmup': warmup,
             'config': {'workload': workload_text(wl, n_seq, n_fp, L, D, args.layers, args.storage, qn, qm, total_rows, extra),
