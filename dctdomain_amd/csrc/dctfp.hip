@@ -696,7 +696,8 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) try {
         if (value != 0 && value != 2) return fail(DCTFP_ERR_INVALID, "stitch_once must be 0 (one launch where the windows allow it) or 2 (one launch per window index)");
         ctx->opt_stitch_once = value;
     } else if (n == "topk_kernel") {
-        if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "topk_kernel must be 0 (two reads, radix select behind it) or 1 (radix select only)");
+        if (value < 0 || value > 2)
+            return fail(DCTFP_ERR_INVALID, "topk_kernel must be 0 (one read; two reads, then the radix select behind it), 1 (radix select only) or 2 (two reads first)");
         ctx->opt_topk_kernel = value;
     } else if (n == "row_select") {
         if (value != 0 && value != 1) return fail(DCTFP_ERR_INVALID, "row_select must be 0 (by shape) or 1 (the radix select whatever the shape)");
@@ -2005,8 +2006,20 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
     stg.pending = true;
     const TopkJob* djobs = (const TopkJob*)tab.p;
     if (n_short > 0) {
-        if (ctx->opt_topk_kernel != 1) {   // two reads of the map; what it hands back (out_n = -1) the radix select redoes
-            hipLaunchKernelGGL(contact_topk2_kernel, dim3((unsigned)n_short), dim3(1024), 0, stream, djobs, out_i, out_j, out_v, out_n);
+        if (ctx->opt_topk_kernel != 1) {   // one read of the map (0; 2 = straight to the two-read kernel of round 4); what a kernel hands
+            // back (out_n = -1) the next one redoes: the two-read kernel, then the radix select
+            if (ctx->opt_topk_kernel == 0) {   // (each build leaves the jobs outside its range of k to the other)
+                constexpr int kSmallK = 1400;
+                bool any_small = false, any_large = false;
+                for (int32_t q = 0; q < n_short; ++q) (h[q].k <= kSmallK ? any_small : any_large) = true;
+                if (any_small)
+                    hipLaunchKernelGGL((contact_topk1_kernel<8>), dim3((unsigned)n_short), dim3(512), 0, stream, djobs, out_i, out_j, out_v, out_n, 0, kSmallK);
+                if (any_large)
+                    hipLaunchKernelGGL((contact_topk1_kernel<16>), dim3((unsigned)n_short), dim3(1024), 0, stream, djobs, out_i, out_j, out_v, out_n,
+                                       kSmallK + 1, 0x7fffffff);
+            }
+            hipLaunchKernelGGL(contact_topk2_kernel, dim3((unsigned)n_short), dim3(1024), 0, stream, djobs, out_i, out_j, out_v, out_n,
+                               ctx->opt_topk_kernel == 0 ? 1 : 0);
             hipLaunchKernelGGL(contact_topk_kernel, dim3((unsigned)n_short), dim3(1024), 0, stream, djobs, out_i, out_j, out_v, out_n, 1);
         } else {
             hipLaunchKernelGGL(contact_topk_kernel, dim3((unsigned)n_short), dim3(1024), 0, stream, djobs, out_i, out_j, out_v, out_n, 0);

@@ -2719,42 +2719,94 @@ __global__ __launch_bounds__(1024) void row_select_kernel(const int32_t* __restr
 // values) selects among those.  A segment with fewer than k entries pads its candidates with (INT32_MAX, INT32_MAX), which
 // lose every tie.
 constexpr int kSelectCap = 4096;   // candidates the LDS holds
-struct SelectShared {
-    uint32_t cnt[128];  // one counter per counting step: no reset, one barrier per step
+constexpr int kSelectCounters = 128;
+template <int NWAVES>
+struct SelectSharedT {
+    uint32_t cnt[kSelectCounters];  // one counter per counting step: no reset, one barrier per step
     uint32_t bound, row_min, pos, fill;
+    uint32_t hist[2][NWAVES * 64];  // kth_smallest: a 64-bin histogram per wave, two sets in turn
+    uint32_t wave_val[NWAVES], wave_cnt[NWAVES];
 };
+typedef SelectSharedT<16> SelectShared;
 __device__ inline uint32_t lane_votes(bool p) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
 
-// The kk-th smallest of E keys per thread by bisection in [lo, hi] (which must hold it; n_less = count(key < lo) on entry,
-// = count(key < result) on return).  Slots without an entry hold 0xffffffff.
-template <int E>
-__device__ inline uint32_t kth_smallest(const uint32_t (&key)[E], uint32_t lo, uint32_t hi, uint32_t& n_less, uint32_t kk, SelectShared& sh,
+// The kk-th smallest of E keys per thread in [lo, hi] (which must hold it; n_less = count(key < lo) on entry, = count(key <
+// result) on return).  Slots without an entry hold 0xffffffff.
+// By HISTOGRAM passes (round 5): a pass sorts the keys of [lo, hi] into 64 equal bins -- every wave into a histogram of its own
+// in LDS (ds_add without return: no wave waits for another's counter, no two waves share one), one barrier, then every wave
+// adds the histograms bin by bin (lane = bin), scans them across its lanes and keeps the bin that holds the answer: six bits of
+// the range per barrier.  The binary search this replaces took one bit per barrier (32 steps from the full key range: a third of
+// the contact top-k's time, most of the row select's after its single read); counting fifteen thresholds per step on the scalar
+// unit (compare, lane mask, popcount, add per key and threshold) was slower still -- the scalar unit is one per CU.
+template <int E, typename SH>
+__device__ inline uint32_t kth_smallest(const uint32_t (&key)[E], uint32_t lo, uint32_t hi, uint32_t& n_less, uint32_t kk, SH& sh,
                                         int& step) {
-    const int lane = threadIdx.x & 63;
-    while (lo < hi) {   // smallest T with count(key <= T) >= kk
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        uint32_t c = 0;    // (empty slots hold 0xffffffff and mid < hi: never counted)
+    const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6);
+    const int n_waves = (int)((blockDim.x + 63u) >> 6);
+    while (lo < hi) {
+        const uint32_t span = hi - lo;
+        const int sft = max(0, 26 - (int)__builtin_clz(span));       // bit_width(span) - 6: bin = (key - lo) >> sft < 64
+        uint32_t* __restrict__ h = sh.hist[step & 1];
+        h[wave * 64 + lane] = 0;   // (the LDS operations of one wave complete in order: my wave's row is clear before it counts)
 #pragma unroll
-        for (int j = 0; j < E; ++j) c += lane_votes(key[j] <= mid);
-        if (lane == 0) atomicAdd(&sh.cnt[step], c);
+        for (int j = 0; j < E; ++j)
+            if (key[j] >= lo && key[j] <= hi) atomicAdd(&h[wave * 64 + (int)((key[j] - lo) >> sft)], 1u);
         __syncthreads();
-        c = sh.cnt[step];
-        ++step;
-        if (c >= kk) hi = mid;
-        else {
-            lo = mid + 1;
-            n_less = c;
+        uint32_t cum = 0;
+        for (int w = 0; w < n_waves; ++w) cum += h[w * 64 + lane];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {   // inclusive prefix sums over the bins
+            const uint32_t up = (uint32_t)__shfl_up((int)cum, off);
+            cum += lane >= off ? up : 0u;
         }
+        const unsigned long long ok = __builtin_amdgcn_ballot_w64(n_less + cum >= kk);   // (not empty: count(key <= hi) >= kk)
+        const int b = ok != 0 ? (int)__builtin_ctzll(ok) : 63;
+        if (b > 0) n_less += (uint32_t)__builtin_amdgcn_readlane((int)cum, b - 1);
+        lo += (uint32_t)b << sft;
+        hi = min(hi, lo + ((1u << sft) - 1u));
+        ++step;   // (the next pass takes the other set of histograms: a wave still adding up this one is not disturbed)
     }
     return lo;
+}
+
+// The same for ONE wave on its own keys (no barrier; `h` = 64 counters of its own), at most `passes` passes: returns the upper
+// end of the range the answer is known to lie in -- the answer itself once the range has shrunk to one key.
+template <int E>
+__device__ inline uint32_t wave_kth_upper(const uint32_t (&key)[E], uint32_t lo, uint32_t hi, uint32_t kk, uint32_t* __restrict__ h, int passes) {
+    const int lane = threadIdx.x & 63;
+    uint32_t n_less = 0;
+    for (int p = 0; p < passes && lo < hi; ++p) {
+        const uint32_t span = hi - lo;
+        const int sft = max(0, 26 - (int)__builtin_clz(span));
+        h[lane] = 0;
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if (key[j] >= lo && key[j] <= hi) atomicAdd(&h[(int)((key[j] - lo) >> sft)], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t cum = h[lane];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)cum, off);
+            cum += lane >= off ? up : 0u;
+        }
+        const unsigned long long ok = __builtin_amdgcn_ballot_w64(n_less + cum >= kk);
+        const int b = ok != 0 ? (int)__builtin_ctzll(ok) : 63;
+        if (b > 0) n_less += (uint32_t)__builtin_amdgcn_readlane((int)cum, b - 1);
+        lo += (uint32_t)b << sft;
+        hi = min(hi, lo + ((1u << sft) - 1u));
+        __builtin_amdgcn_wave_barrier();
+    }
+    return hi;
 }
 
 // The kk smallest of E (key, column) pairs per thread, ties to the lowest columns: T = the kk-th smallest key by bisection
 // in [lo, hi] (n_less = count(key < lo) on entry), then emit(output slot, key, column) for each of them.  Slots without an entry hold
 // key 0xffffffff and a column > col_hi; `valid(j)` tells them from real entries of that value.
-template <int E, typename ColF, typename ValidF, typename EmitF>
+template <int E, typename SH, typename ColF, typename ValidF, typename EmitF>
 __device__ inline void bisect_emit(const uint32_t (&key)[E], ColF col_of, ValidF valid, uint32_t lo, uint32_t hi, uint32_t n_less,
-                                   uint32_t col_hi, uint32_t kk, SelectShared& sh, int& step, EmitF emit) {
+                                   uint32_t col_hi, uint32_t kk, SH& sh, int& step, EmitF emit) {
     const int lane = threadIdx.x & 63;
     auto total = [&](uint32_t w) {   // wave counts -> sum over the workgroup; every thread gets it
         if (lane == 0) atomicAdd(&sh.cnt[step], w);
@@ -2763,7 +2815,7 @@ __device__ inline void bisect_emit(const uint32_t (&key)[E], ColF col_of, ValidF
         ++step;
         return t;
     };
-    const uint32_t thr = kth_smallest<E>(key, lo, hi, n_less, kk, sh, step);
+    const uint32_t thr = kth_smallest<E, SH>(key, lo, hi, n_less, kk, sh, step);
     const uint32_t need = kk - n_less;   // entries equal to thr still wanted (>= 1): the ones in the lowest columns
     uint32_t ties = 0;
 #pragma unroll
@@ -2816,7 +2868,7 @@ __global__ __launch_bounds__(TH, 4) void row_select_reg_kernel(const int32_t* __
     int32_t* __restrict__ ov = out_val + ((size_t)row * n_seg + seg) * k;
     int32_t* __restrict__ oi = out_idx + ((size_t)row * n_seg + seg) * k;
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int q = tid; q < 128; q += TH) sh.cnt[q] = 0;
+    for (int q = tid; q < kSelectCounters; q += TH) sh.cnt[q] = 0;
     if (tid == 0) {
         sh.pos = 0;
         sh.fill = 0;
@@ -3087,11 +3139,12 @@ __device__ inline void topk2_run(const TopkJob& job, SelectShared& sh, uint32_t*
 #ifndef DCTFP_TEMPLATES_ONLY   // (a plain kernel: defined in dctfp.hip only, the kernel-family units see the templates)
 __global__ __launch_bounds__(1024, DCTFP_TOPK_WAVES) void contact_topk2_kernel(const TopkJob* __restrict__ jobs, int32_t* __restrict__ out_i,
                                                               int32_t* __restrict__ out_j, float* __restrict__ out_v,
-                                                              int32_t* __restrict__ out_n) {
+                                                              int32_t* __restrict__ out_n, int redo_only) {
     __shared__ SelectShared sh;
     __shared__ uint32_t s_key[kTopkCap], s_ij[kTopkCap];
     const TopkJob job = jobs[blockIdx.x];
-    if (threadIdx.x < 128) sh.cnt[threadIdx.x] = 0;
+    if (redo_only && out_n[job.orig] >= 0) return;   // (behind contact_topk1_kernel: only what that one handed back)
+    if (threadIdx.x < kSelectCounters) sh.cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         sh.pos = 0;
         sh.fill = 0;
@@ -3111,5 +3164,329 @@ __global__ __launch_bounds__(1024, DCTFP_TOPK_WAVES) void contact_topk2_kernel(c
     else topk2_run<8>(job, sh, s_key, s_ij, out_i, out_j, out_v, out_n);
 }
 #endif
+
+// ---------------------------------------------------------------------------
+// Contact top-k in ONE read of the map (round 5; the kernel above streams the candidate triangle twice, 4 bytes per lane).
+//   1. a SAMPLE of the triangle stays in registers: four 16-byte loads per lane (VEC4) = 16 384 entries per map, from four of
+//      every wave's row pairs spread over its rows, a different column chunk of each (the waves interleave rows, so the sample
+//      is stratified over the whole map and over the distance from the diagonal).  With n_s valid entries among them and N in
+//      the triangle, the r-th smallest sample key, r = ceil(2 kk n_s / N), is a bound b0 that about 2 kk keys of the map stay
+//      under (sixteen-way selection in registers: 8 barriers) -- the whole map in the sample: r = kk, b0 exact;
+//   2. the rest of the triangle streams by ONCE (the sampled slots are not read again): keys <= b0 go to LDS with their (i, j),
+//      the sampled ones straight from their registers;
+//   3. kk <= candidates <= kTopkCap: the kk smallest among them, ties by (i, j), exactly as in the two-read kernel (every key
+//      equal to the kk-th is <= b0, so all ties are among the candidates).  Fewer than kk (the sample misjudged the map: for
+//      independent entries a nine-sigma event, any map is possible) or more than the LDS holds (plateaus of equal values),
+//      k > 3000, L > 65 535: out_n = -1, and the two-read kernel launched behind this one (redo_only) does that protein.
+// A wave takes its n-th row from the top together with its n-th from the bottom as above; the slots (row, chunk) of all its
+// pairs form one sequence, G of them requested at once whatever pair they belong to (at L = 500 a pair has three 256-column
+// chunks: per-pair batches would leave three loads in flight).
+// ---------------------------------------------------------------------------
+template <bool VEC4, int NW>
+struct TopkSlots {   // the (row, chunk) sequence of one wave; everything here is wave-uniform
+    static constexpr int W = VEC4 ? 4 : 1, CH = 64 * W;
+    int L, wave, n_rows, n_pairs;
+    int n, sl, ra, rb, ca, cb;
+    __device__ inline static int first_col(int i) { return VEC4 ? ((i + 5) & ~3) : i + 5; }
+    __device__ inline int chunks(int i) const { return (L - first_col(i) + CH - 1) / CH; }
+    __device__ inline void set_pair(int pair) {
+        n = pair;
+        sl = 0;
+        if (pair < n_pairs) {
+            ra = wave + NW * pair;
+            rb = wave + NW * (n_rows - 1 - pair);
+            ca = chunks(ra);
+            cb = rb != ra ? chunks(rb) : 0;
+        } else {
+            ra = rb = 0;
+            ca = cb = 0;
+        }
+    }
+    __device__ inline void init(int L_, int wave_) {
+        L = L_;
+        wave = wave_;
+        const int last_row = L - 6;
+        n_rows = last_row >= wave ? (last_row - wave) / NW + 1 : 0;   // rows wave, wave + NW, ...
+        n_pairs = (n_rows + 1) / 2;
+        set_pair(0);
+    }
+    __device__ inline bool done() const { return n >= n_pairs; }
+    __device__ inline int row() const { return sl < ca ? ra : rb; }
+    __device__ inline int col0() const { return first_col(row()) + CH * (sl < ca ? sl : sl - ca); }   // lane 0's first column
+    __device__ inline void next() {
+        if (++sl >= ca + cb) set_pair(n + 1);
+    }
+};
+
+template <bool VEC4, int NW>
+__device__ inline void topk1_run(const TopkJob& job, SelectSharedT<NW>& sh, uint32_t* __restrict__ s_key, uint32_t* __restrict__ s_ij,
+                                 int32_t* __restrict__ out_i, int32_t* __restrict__ out_j, float* __restrict__ out_v,
+                                 int32_t* __restrict__ out_n) {
+    constexpr int W = VEC4 ? 4 : 1, NS = 4;   // entries per lane and load; sample loads per lane
+    constexpr int WCAP = 512;                // candidates a wave may keep (its own part of the LDS buffer: no atomics)
+    constexpr int TH = NW * 64;
+    typedef typename std::conditional<VEC4, v4f, float>::type LV;
+    const int L = job.n_res;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t kk = (uint32_t)job.k;
+    auto ikey = [](float v) { return ~topk_key(v); };
+    // A load = 64 lanes x W columns of ONE row through a descriptor that ends with that row: the lanes past column L -- a chunk
+    // is 256 columns, a row's candidates rarely a multiple of it -- read 0 WITHOUT a memory access (through a descriptor of the
+    // whole map they fetched the head of the next row: + 35 % of HBM traffic at L = 500).  i < 0: no such slot, nothing read.
+    auto load = [&](int i, int c0) -> LV {   // lane l: columns c0 + W l .. + W - 1 of row i
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.map) + (int64_t)max(i, 0) * job.ld, 0,
+                                                                               i >= 0 ? L * 4 : 0, 0x00020000);
+        if constexpr (VEC4) return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rb, lane * 16, c0 * 4, 0));
+        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, c0 * 4, 0));
+    };
+    auto elem = [](const LV& v, int e) -> float {
+        if constexpr (VEC4) return v[e];
+        else return v;
+    };
+    // ---- 1. the sample: slot (u + 1) mod slots-of-the-pair of pair u * stride, u < NS
+    TopkSlots<VEC4, NW> it;
+    it.init(L, wave);
+    const int stride = it.n_pairs >= NS ? it.n_pairs / NS : 1;
+    int s_row[NS], s_c0[NS], s_pair[NS], s_slot[NS];
+    LV sv[NS];
+    // (slots first, loads after them in straight-line code: a load under a branch -- even a wave-uniform one -- is waited for
+    //  before the next is issued, a round trip to HBM per slot; a slot that does not exist reads past the end of the buffer: 0,
+    //  no memory access)
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        TopkSlots<VEC4, NW> p = it;
+        p.set_pair(u * stride);
+        s_pair[u] = s_slot[u] = -1;
+        s_row[u] = -1;
+        s_c0[u] = 0;
+        if (!p.done()) {
+            const int want = (u + 1) % (p.ca + p.cb);
+            for (int q = 0; q < want; ++q) p.next();
+            s_pair[u] = p.n;
+            s_slot[u] = p.sl;
+            s_row[u] = p.row();
+            s_c0[u] = p.col0();
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) sv[u] = load(s_row[u], s_c0[u]);
+    uint32_t sk[NS * W];
+    uint32_t n_w = 0, s_valid = 0;   // valid sample entries of this wave; bit u W + e: that sample slot of mine holds a candidate
+    uint32_t kmin = 0xffffffffu, kmax = 0;
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            const int j = s_c0[u] + W * lane + e;
+            const bool valid = s_pair[u] >= 0 && j >= s_row[u] + 5 && j < L;
+            const uint32_t x = ikey(elem(sv[u], e));
+            sk[u * W + e] = valid ? x : 0xffffffffu;
+            s_valid |= (valid ? 1u : 0u) << (u * W + e);
+            n_w += lane_votes(valid);
+            kmin = min(kmin, valid ? x : 0xffffffffu);
+            kmax = max(kmax, valid ? x : 0u);
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off));
+    }
+    // Every wave bounds the map from ITS sample (its rows are spread over the whole map): with n_w valid entries of the N in the
+    // triangle, the r-th smallest key of the sample, r = ceil(2 kk n_w / N), is a value that about 2 kk keys of the map stay
+    // under.  Wave-local (three histogram passes over the wave's own 64 counters: the range to 1 / 2^18, its upper end taken),
+    // no barrier; the workgroup then takes the 12th smallest of its 16 wave bounds.  The whole map in the samples (L < ~140):
+    // exact selection below instead.
+    const uint64_t n_all = (uint64_t)(L - 5) * (uint64_t)(L - 4) / 2;
+    {
+        uint32_t rank = (uint32_t)min((uint64_t)n_w, (3ull * kk * n_w + 2 * n_all - 1) / (2 * n_all));
+        rank = max(rank, min(n_w, 4u));
+        const uint32_t wb = n_w > 0 && kmin <= kmax ? wave_kth_upper<NS * W>(sk, kmin, kmax, rank, &sh.hist[0][wave * 64], 3) : 0xffffffffu;
+        if (lane == 0) {
+            sh.wave_val[wave] = wb;
+            sh.wave_cnt[wave] = n_w;
+        }
+    }
+    __syncthreads();
+    uint32_t n_s = 0;
+    for (int w = 0; w < NW; ++w) n_s += sh.wave_cnt[w];
+    const bool whole = n_s >= n_all;   // every candidate of the map is in the sample
+    int step = 0;
+    uint32_t bound;
+    if (whole) {
+        uint32_t n_less = 0;
+        bound = kth_smallest<NS * W>(sk, 0u, 0xffffffffu, n_less, kk, sh, step);
+    } else {   // the wave bound three quarters up their sorted list (ties by wave): a little above their median
+        const uint32_t v = sh.wave_val[lane % NW];
+        uint32_t below = 0;
+#pragma unroll
+        for (int m = 0; m < NW; ++m) {
+            const uint32_t vm = (uint32_t)__builtin_amdgcn_readlane((int)v, m);
+            below += (vm < v || (vm == v && m < lane % NW)) ? 1u : 0u;
+        }
+        const unsigned long long pick = __builtin_amdgcn_ballot_w64(lane < NW && below == (uint32_t)(3 * NW / 4 - 1));
+        bound = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_ctzll(pick));
+    }
+#if defined(DCTFP_TOPK1_STOP) && DCTFP_TOPK1_STOP == 1
+    if (tid == 0) out_n[job.orig] = (int)bound;
+    return;
+#endif
+    // ---- 2. keys up to the bound -> this wave's part of the LDS buffer: the sample from its registers, the rest of the triangle
+    // as it streams by.  The stream tests the VALUE against the bound's value (one compare: not below it -- NaNs pass and are
+    // judged by their key like everything that passes); key, validity and position only for what passed.
+    const uint32_t tkey = ~bound;   // topk_key of the bound
+    const float thr = __uint_as_float((tkey & 0x80000000u) ? (tkey & 0x7fffffffu) : ~tkey);
+    uint32_t* __restrict__ wk = s_key + wave * WCAP;
+    uint32_t* __restrict__ wij = s_ij + wave * WCAP;
+    uint32_t w_fill = 0;   // (wave-uniform)
+    auto keep = [&](uint32_t x, bool take, int i, int j) {
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(take);
+        const uint32_t at = w_fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (take && at < (uint32_t)WCAP) {
+            wk[at] = x;
+            wij[at] = ((uint32_t)i << 16) | (uint32_t)j;
+        }
+        w_fill += (uint32_t)__builtin_popcountll(mask);
+    };
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            const bool take = ((s_valid >> (u * W + e)) & 1u) && sk[u * W + e] <= bound;
+            if (__builtin_amdgcn_ballot_w64(take) != 0) keep(__float_as_uint(elem(sv[u], e)), take, s_row[u], s_c0[u] + W * lane + e);
+        }
+    if (!whole) {
+        constexpr int G = VEC4 ? 8 : 12;
+        auto sampled = [&](const TopkSlots<VEC4, NW>& p) {
+            bool hit = false;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) hit |= p.n == s_pair[u] && p.sl == s_slot[u];
+            return hit;
+        };
+        while (!it.done()) {
+            LV v[G];
+            int vi[G], vc[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {   // the next G slots (scalar work only) ...
+                while (!it.done() && sampled(it)) it.next();
+                vi[u] = -1;
+                vc[u] = 0;
+                if (!it.done()) {
+                    vi[u] = it.row();
+                    vc[u] = it.col0();
+                    it.next();
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) v[u] = load(vi[u], vc[u]);   // ... their loads, all in flight together ...
+#pragma unroll
+            for (int u = 0; u < G; ++u) {                                      // ... and what they hold
+                if (vi[u] < 0) continue;   // (wave-uniform)
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    const float x = elem(v[u], e);
+                    if (__builtin_amdgcn_ballot_w64(!(x < thr)) != 0) {   // (a third of a map's registers: nobody in the wave)
+                        const int j = vc[u] + W * lane + e;
+                        keep(__float_as_uint(x), !(x < thr) && j >= vi[u] + 5 && j < L, vi[u], j);   // (the value's bits: its key when it is selected from)
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) sh.wave_cnt[wave] = w_fill;
+    __syncthreads();
+    uint32_t n_cand = 0;
+    bool over = false;
+    for (int w = 0; w < NW; ++w) {
+        n_cand += sh.wave_cnt[w];
+        over |= sh.wave_cnt[w] > (uint32_t)WCAP;
+    }
+#if defined(DCTFP_TOPK1_STOP) && DCTFP_TOPK1_STOP == 2
+    if (tid == 0) out_n[job.orig] = (int)n_cand;
+    return;
+#endif
+    if (n_cand < kk || over) {   // the samples misjudged the map, or plateaus of equal values: the two-read kernel behind this one
+        if (tid == 0) out_n[job.orig] = -1;
+        return;
+    }
+    // (n_cand counts what passed the value test; the few that fail the key test below -- NaNs -- could leave fewer than kk:
+    //  checked again after the keys are known)
+    // ---- 3. the kk smallest of the candidates, ties to the lowest (i, j)
+    constexpr int E = WCAP / 64;   // (NW * WCAP candidate slots over NW * 64 threads)
+    uint32_t ck[E], cij[E];
+    bool have[E];
+    uint32_t cmin = 0xffffffffu;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t p = (uint32_t)(e * TH + tid);
+        have[e] = (p % (uint32_t)WCAP) < sh.wave_cnt[p / (uint32_t)WCAP];
+        // (what passed the stream's value test and is not up to the bound by its KEY -- a NaN of the wrong sign -- is no candidate)
+        const uint32_t xk = have[e] ? ikey(__uint_as_float(s_key[p])) : 0xffffffffu;
+        have[e] = have[e] && xk <= bound;
+        ck[e] = have[e] ? xk : 0xffffffffu;
+        cij[e] = have[e] ? s_ij[p] : 0xffffffffu;
+        cmin = min(cmin, ck[e]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cmin = min(cmin, (uint32_t)__shfl_xor((int)cmin, off));
+    uint32_t n_real = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) n_real += lane_votes(have[e]);
+    if (lane == 0) {
+        atomicMin(&sh.row_min, cmin);
+        atomicAdd(&sh.fill, n_real);
+    }
+    __syncthreads();
+    cmin = sh.row_min;
+    if (sh.fill < kk) {   // (wave-uniform, workgroup-uniform)
+        if (tid == 0) out_n[job.orig] = -1;
+        return;
+    }
+    int32_t* __restrict__ oi = out_i + job.out_off;
+    int32_t* __restrict__ oj = out_j + job.out_off;
+    float* __restrict__ ov = out_v + job.out_off;
+    bisect_emit<E>(ck, [&](int e) { return cij[e]; }, [&](int e) { return have[e]; }, cmin, bound, 0u, 0xfffffffeu, kk, sh,
+                   step, [&](uint32_t pos, uint32_t key_e, uint32_t ij) {
+                       const int i = (int)(ij >> 16), j = (int)(ij & 0xffffu);
+                       oi[pos] = i;
+                       oj[pos] = j;
+                       // the value from its key (1 300 scattered 4-byte reads per map were a fifth of the kernel's HBM traffic);
+                       // only a zero is read back: -0.0 and +0.0 share a key and the caller gets the map's own bits
+                       const uint32_t tk = ~key_e;
+                       const float val = __uint_as_float((tk & 0x80000000u) ? (tk & 0x7fffffffu) : ~tk);
+                       ov[pos] = val == 0.0f ? job.map[(size_t)i * job.ld + j] : val;
+                   });
+    if (tid == 0) out_n[job.orig] = job.k;
+}
+
+// NW = 8: maps up to k = 1 280 (L <= 492 at t = 2.6 ... see the host) in workgroups of 512 threads, 37 KB of LDS: FOUR per CU, so
+// that three stream while one samples or selects (two workgroups of 1024 left the memory pipe idle a third of the time);
+// NW = 16: up to k = 3 000.  A job outside a build's range is left to the other (each launch sees every job).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, DCTFP_TOPK_WAVES) void contact_topk1_kernel(const TopkJob* __restrict__ jobs, int32_t* __restrict__ out_i,
+                                                              int32_t* __restrict__ out_j, float* __restrict__ out_v,
+                                                              int32_t* __restrict__ out_n, int k_from, int k_to) {
+    __shared__ SelectSharedT<NW> sh;
+    __shared__ uint32_t s_key[NW * 512], s_ij[NW * 512];
+    const TopkJob job = jobs[blockIdx.x];
+    if (job.k > 0 && job.n_res >= 6 && (job.k < k_from || job.k > k_to)) return;
+    for (int q = threadIdx.x; q < kSelectCounters; q += NW * 64) sh.cnt[q] = 0;
+    if (threadIdx.x == 0) {
+        sh.pos = 0;
+        sh.fill = 0;
+        sh.row_min = 0xffffffffu;
+    }
+    __syncthreads();
+    if (job.k <= 0 || job.n_res < 6) {
+        if (threadIdx.x == 0) out_n[job.orig] = 0;
+        return;
+    }
+    if (job.k > 3000 || job.n_res > 65535 || (int64_t)job.n_res * job.ld >= ((int64_t)1 << 29)) {   // (one and a half times k candidates must
+        // fit the LDS / (i, j) beyond 16 bits each / a map beyond the 32-bit byte offsets of the buffer loads)
+        if (threadIdx.x == 0) out_n[job.orig] = -1;
+        return;
+    }
+    if ((reinterpret_cast<uintptr_t>(job.map) & 15u) == 0 && (job.ld & 3) == 0) topk1_run<true, NW>(job, sh, s_key, s_ij, out_i, out_j, out_v, out_n);
+    else topk1_run<false, NW>(job, sh, s_key, s_ij, out_i, out_j, out_v, out_n);
+}
 
 }  // namespace dctfp
