@@ -39,16 +39,17 @@ EXPERIMENTS_LIB_PATH = os.path.join(PKG_DIR, 'libdctfp_experiments.so')
 #: compiles side by side (the stage-A instantiations alone are two thirds of it).  `twin` = units that differ in
 #: libdctfp_experiments.so (-DDCTFP_EXPERIMENTS: option names, extra walk-kernel builds); the others are compiled once and
 #: linked into both libraries.
-UNITS = ['dctfp.hip', 'k_walk.hip', 'k_gen.hip', 'k_stage_b.hip', 'k_stage_a_f32.hip', 'k_stage_a_f64.hip', 'k_stage_a_f16.hip',
+UNITS = ['dctfp.hip', 'k_walk.hip', 'k_gen.hip', 'k_reccut.hip', 'k_stage_b.hip', 'k_stage_a_f32.hip', 'k_stage_a_f64.hip', 'k_stage_a_f16.hip',
          'k_stage_a_bf16.hip']
 TWIN_UNITS = ('dctfp.hip', 'k_walk.hip')
-HEADERS = [os.path.join(CSRC, 'kernels.hip.h'), os.path.join(CSRC, 'launch.h'), os.path.join(ROOT, 'include', 'dctfp.h')]
+HEADERS = [os.path.join(CSRC, 'kernels.hip.h'), os.path.join(CSRC, 'launch.h'), os.path.join(ROOT, 'include', 'dctfp.h'),
+           os.path.join(CSRC, 'reccut_kernel.hip.h')]
 OBJ_DIR = os.path.join(ROOT, 'build', 'dctfp_objs')
 
 
 def kernel_sources():
     """Every file the device code and its dispatch come from (what a PMC traffic measurement is stamped with)."""
-    return [os.path.join(CSRC, u) for u in UNITS] + HEADERS[:2]
+    return [os.path.join(CSRC, u) for u in UNITS] + HEADERS[:2] + HEADERS[3:]
 
 
 def sha256_of(path: str) -> str:

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "launch.h"   // (kernels.hip.h, the parameter blocks and the launchers of the kernel families built in their own units)
+#include "reccut_kernel.hip.h"   // (CutJob, table sizes; the kernel itself is instantiated in k_reccut.hip)
 
 using namespace dctfp;
 using namespace dctfp_host;
@@ -207,6 +208,17 @@ struct dctfp_ctx {
     int n_cu = 256;  // compute units of the device (workgroup slots of the walk kernel = n_cu x workgroups per CU)
     void *trace_dev = nullptr, *trace_host = nullptr;  // instrumented build only (walk_trace)
     int64_t trace_waves = 0;
+    DevBuf cut_ws;   // dctfp_reccut: adjacency lists and node stacks of a batch
+    hipStream_t cut_stream[2] = {nullptr, nullptr};   // ... its two larger size classes run beside the small one
+    hipEvent_t cut_ev[3] = {nullptr, nullptr, nullptr};
+    int ensure_cut_streams() {
+        if (cut_stream[0]) return DCTFP_OK;
+        for (int i = 0; i < 2; ++i)
+            if (hipStreamCreateWithFlags(&cut_stream[i], hipStreamNonBlocking) != hipSuccess) { cut_stream[i] = nullptr; set_err("hipStreamCreate(cut) failed"); return DCTFP_ERR_HIP; }
+        for (int i = 0; i < 3; ++i)
+            if (hipEventCreateWithFlags(&cut_ev[i], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); return DCTFP_ERR_HIP; }
+        return DCTFP_OK;
+    }
     int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0, opt_ab_taper = 4, opt_ab_align = 2, opt_l1_kernel = 0, opt_row_select = 0, opt_stitch_once = 0, opt_topk_kernel = 0;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     int64_t walk_launches = 0;  // walk-kernel launches so far (a call split at a giant domain ends on the two-kernel path)
@@ -611,6 +623,10 @@ int dctfp_destroy(dctfp_ctx* ctx) try {
             if (ctx->ev_b[i]) (void)hipEventDestroy(ctx->ev_b[i]);
         }
     }
+    for (int i = 0; i < 3; ++i)
+        if (ctx->cut_ev[i]) (void)hipEventDestroy(ctx->cut_ev[i]);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->cut_stream[i]) (void)hipStreamDestroy(ctx->cut_stream[i]);
     delete ctx;
     return DCTFP_OK;
 } DCTFP_GUARD("dctfp_destroy")
@@ -2113,6 +2129,107 @@ int dctfp_contact_sort(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
     }
     return mark_table_used(ctx, buf, stream);
 } DCTFP_GUARD("dctfp_contact_sort")
+
+int64_t dctfp_reccut_room(int32_t n_res) {
+    // {status / n_domains} + per domain {n_segs} + per segment {first, last}: domains hold >= 22 residues, a cut adds at most two
+    // segments
+    const int64_t doms = n_res > 0 ? n_res / kCutMinSize + 1 : 1;
+    return 2 + doms + 2 * (2 * doms + 1);
+}
+
+int dctfp_reccut(dctfp_ctx* ctx, const int32_t* n_res, int32_t n_prot, const int32_t* ci, const int32_t* cj, const float* cv,
+                 const int64_t* offs, double cut1, double cut2, int32_t* out, const int64_t* out_offs, void* stream_v) try {
+    if (!ctx || !n_res || !offs || !out || !out_offs) return fail(DCTFP_ERR_INVALID, "dctfp_reccut: NULL argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_prot < 0) return fail(DCTFP_ERR_INVALID, "dctfp_reccut: negative count");
+    if (n_prot == 0) return DCTFP_OK;
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // jobs by LDS class (512 / 1024 / 2048 residues), each class one launch; scratch: adjacency lists + node stacks
+    std::vector<int32_t> order((size_t)n_prot);
+    int32_t count[3] = {0, 0, 0};
+    std::vector<uint8_t> cls((size_t)n_prot);
+    size_t adj_total = 0;
+    for (int32_t p = 0; p < n_prot; ++p) {
+        const int64_t nc = offs[p + 1] - offs[p];
+        if (n_res[p] < 0 || nc < 0 || nc > 0x7fffffff || (nc > 0 && (!ci || !cj || !cv)))
+            return fail(DCTFP_ERR_INVALID, "dctfp_reccut: protein %d: bad sizes", p);
+        if (out_offs[p + 1] - out_offs[p] < 4) return fail(DCTFP_ERR_INVALID, "dctfp_reccut: protein %d: output room below 4", p);
+        cls[(size_t)p] = (uint8_t)reccut_class_of(n_res[p], nc);
+        ++count[cls[(size_t)p]];
+        adj_total += 2 * (size_t)nc + 6 * (size_t)std::max(n_res[p], 0);
+    }
+    int32_t first[3] = {0, count[0], count[0] + count[1]};
+    {
+        int32_t at[3] = {first[0], first[1], first[2]};
+        for (int32_t p = 0; p < n_prot; ++p) order[(size_t)at[cls[(size_t)p]]++] = p;
+    }
+    const size_t stack_ints = (size_t)kCutStack * kCutNodeInts;
+    const size_t ws_bytes = align_up(adj_total * sizeof(uint32_t), 16) + (size_t)n_prot * stack_ints * sizeof(int32_t);
+    int rc = ctx->cut_ws.ensure(ws_bytes);
+    if (rc) return rc;
+    const int buf = ctx->flip;
+    Staging& stg = ctx->staging[buf];
+    DevBuf& tab = ctx->tables[buf];
+    ctx->flip ^= 1;
+    rc = stg.ensure((size_t)n_prot * sizeof(CutJob));
+    if (rc) return rc;
+    rc = tab.ensure((size_t)n_prot * sizeof(CutJob));
+    if (rc) return rc;
+    CutJob* h = (CutJob*)stg.p;
+    uint32_t* adj = (uint32_t*)ctx->cut_ws.p;
+    int32_t* stacks = (int32_t*)((char*)ctx->cut_ws.p + align_up(adj_total * sizeof(uint32_t), 16));
+    size_t adj_at = 0;
+    for (int32_t q = 0; q < n_prot; ++q) {
+        const int32_t p = order[(size_t)q];
+        const int64_t nc = offs[p + 1] - offs[p];
+        CutJob& j = h[q];
+        j.ci = ci ? ci + offs[p] : nullptr;
+        j.cj = cj ? cj + offs[p] : nullptr;
+        j.cv = cv ? cv + offs[p] : nullptr;
+        j.adj = adj + adj_at;
+        adj_at += 2 * (size_t)nc + 6 * (size_t)std::max(n_res[p], 0);
+        j.stack = stacks + (size_t)q * stack_ints;
+        j.out = out + out_offs[p];
+        j.timing = nullptr;
+#ifdef DCTFP_CUT_TIMING
+        j.timing = ctx->degenerate + 1;   // (instrumented build: the context's spare device counters)
+#endif
+        j.n_contacts = (int32_t)nc;
+        j.n_res = n_res[p];
+        j.out_cap = (int32_t)std::min<int64_t>(out_offs[p + 1] - out_offs[p], 0x7fffffff);
+        j.reserved = 0;
+    }
+    HIP_TRY(hipMemcpyAsync(tab.p, stg.p, (size_t)n_prot * sizeof(CutJob), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(stg.ev, stream));
+    stg.pending = true;
+    const CutJob* d = (const CutJob*)tab.p;
+    // A class's launch lasts as long as its slowest protein (one workgroup each): the two larger classes run on streams of their
+    // own beside the small one, and the caller's stream continues after all three.
+    const bool beside = count[1] + count[2] > 0 && count[0] + (count[1] > 0 ? 1 : 0) + (count[2] > 0 ? 1 : 0) > 1;
+    if (beside) {
+        rc = ctx->ensure_cut_streams();
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ctx->cut_ev[0], stream));
+    }
+    for (int c = 2; c >= 0; --c) {
+        if (count[c] == 0) continue;
+        hipStream_t s = beside && c > 0 ? ctx->cut_stream[c - 1] : stream;
+        if (s != stream) HIP_TRY(hipStreamWaitEvent(s, ctx->cut_ev[0], 0));
+        for (int32_t done = 0; done < count[c]; done += 65535 * 16) {
+            const unsigned n = (unsigned)std::min<int32_t>(count[c] - done, 65535 * 16);
+            LaunchError le;
+            rc = launcher_rc(launch_reccut(c, d + first[c] + done, n, cut1, cut2, s, &le), le);
+            if (rc) return rc;
+            HIP_TRY(hipGetLastError());
+        }
+        if (s != stream) {
+            HIP_TRY(hipEventRecord(ctx->cut_ev[c], s));
+            HIP_TRY(hipStreamWaitEvent(stream, ctx->cut_ev[c], 0));
+        }
+    }
+    return mark_table_used(ctx, buf, stream);
+} DCTFP_GUARD("dctfp_reccut")
 
 }  // extern "C"
 

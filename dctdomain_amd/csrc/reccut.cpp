@@ -449,6 +449,58 @@ extern "C" {
 
 int32_t reccut_contact_weight(float prob) { return contact_weight(prob); }
 
+/* The same in exact arithmetic, no text round trip (what the GPU kernel computes: csrc/reccut_kernel.hip.h): p * 10^6 is exact
+ * in double, printf rounds it half-to-even, strtod returns the double nearest to n / 10^6. */
+int32_t reccut_contact_weight_exact(float prob) {
+    const double n6 = std::rint((double)prob * 1.0e6);
+    const double v = n6 / 1.0e6;
+    volatile double prod = v * 100.0;
+    return (int)(prod + 0.5);
+}
+
+/* Strings of dctfp_reccut's encoded results (include/dctfp.h), packed like reccut_predict_packed's. */
+int reccut_format_packed(int64_t n_prot, const int32_t* enc, const int64_t* enc_off, char* out, int64_t out_cap, int64_t* out_off,
+                         int32_t* n_domains, uint8_t* needs_host) {
+    if (n_prot < 0 || !enc || !enc_off || !out || !out_off || !needs_host) return RECCUT_ERR_INVALID;
+    int64_t at = 0;
+    char buf[48];
+    for (int64_t p = 0; p < n_prot; ++p) {
+        out_off[p] = at;
+        const int32_t* e = enc + enc_off[p];
+        const int64_t room = enc_off[p + 1] - enc_off[p];
+        needs_host[p] = 0;
+        if (n_domains) n_domains[p] = 0;
+        if (room < 1 || e[0] < 1) {
+            needs_host[p] = 1;
+            continue;
+        }
+        int64_t q = 1;
+        bool ok = true;
+        const int64_t begin = at;
+        for (int32_t d = 0; d < e[0] && ok; ++d) {
+            if (q >= room) { ok = false; break; }
+            const int32_t ns = e[q++];
+            if (ns < 1 || q + 2 * (int64_t)ns > room) { ok = false; break; }
+            for (int32_t s = 0; s < ns; ++s) {
+                const int n = snprintf(buf, sizeof buf, "%s%d-%d", s ? "," : "", e[q] + 1, e[q + 1] + 1);
+                q += 2;
+                if (at + n + 1 > out_cap) return RECCUT_ERR_BUFFER;
+                memcpy(out + at, buf, (size_t)n);
+                at += n;
+            }
+            out[at++] = ';';
+        }
+        if (!ok) {
+            at = begin;
+            needs_host[p] = 1;
+            continue;
+        }
+        if (n_domains) n_domains[p] = e[0];
+    }
+    out_off[n_prot] = at;
+    return RECCUT_OK;
+}
+
 int reccut_predict(int32_t n_res, const int32_t* ci, const int32_t* cj, const float* prob, int64_t n_contacts,
                    double cut1, double cut2, char* out, int64_t out_cap, int32_t* n_domains) {
     if (!out || out_cap < 1) return RECCUT_ERR_INVALID;

@@ -9,7 +9,8 @@ What changes underneath: the reference embeds on the GPU, copies ev
 the host, pickles it into a ``multiprocessing.Pool`` and fingerprints one protein per worker call
 (:36-51).  Here the embeddings stay on the GPU; a flush of many proteins is fingerprinted by one
 batched contact top-k, one threaded in-process RecCut call and one ``dctfp_quantize`` launch
-(``fingerprint_batch``).  ``--cpu`` sizes the RecCut thread pool, ``--gpu G`` starts one process
+(``fingerprint_batch``; round 5: the domain cutter's recursion runs on the GPU too, ``dctfp_reccut``).  ``--cpu`` sizes the thread pool of
+the host cutter (what the GPU one hands back: proteins above 2 048 residues), ``--gpu G`` starts one process
 per GPU over disjoint, length-balanced shards; a single writer (the parent) fills the database in
 sequence order, one transaction per flush (``OrderedWriter``), so the files are identical for every G and an
 interrupted build resumes where it stopped (``fpcount``, src/database.py:150, :211-213).
@@ -48,6 +49,10 @@ def stage(name: str):
         STAGE_SECONDS[name] += time.perf_counter() - t0
 
 
+from operator import attrgetter as _attrgetter
+_IS_CUDA, _DTYPE = _attrgetter('is_cuda'), _attrgetter('dtype')
+_KEPT_DTYPES = {torch.float32, torch.float64, torch.float16, torch.bfloat16}
+
 LAYERS = [15, 21]                 # src/make_db.py:78, :138
 QDIM = [3, 80, 3, 80]             # src/make_db.py:30
 THRESHOLD = 2.6                   # src/make_db.py:29
@@ -79,26 +84,34 @@ def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, thres
     maps = [reccut._contact_tensor(fp.contacts, n) for fp, n in zip(fps, lens)]
     ctx = _lib.get_context(maps[0].device.index)
     ctx.get_option('degenerate_seen')                          # (the flag is the context's: drop what earlier callers left unread)
-    offs, ci, cj, cv = reccut.top_contacts_batch(maps, threshold, sort=False, own=False)   # (views: used up before this call returns)
-    # RecCut is host C++ (ctypes releases the GIL): it runs on its own threads while this one builds the embedding tables
-    cut = {}
+    # Contact selection and the domain cutter's recursion both run on the GPU (round 5: dctfp_contact_topk + dctfp_reccut; the
+    # host library cost 9 us per protein on 16 threads, and the selected contacts had to come over for it); while the kernels
+    # run, this thread builds the embedding tables.  What comes back is a few ints per domain.
+    built = {}
 
-    def run_reccut():
-        try:
-            cut['doms'] = reccut.domains_from_contacts(lens, offs, ci, cj, cv, threads=max(1, threads))
-        except BaseException as exc:       # noqa: BLE001 -- re-raised in the caller's thread below
-            cut['error'] = exc
-
-    worker = threading.Thread(target=run_reccut)
-    worker.start()
-    try:
+    def build_tables():
         keys0 = list(fps[0].embed.keys())
-        mats = [[_to_device_matrix(fp.embed[k], keep_half=True) for fp in fps] for k in keys0]
-        layers = [LayerBatch(mats[i], qdim[2 * i], qdim[2 * i + 1]) for i in range(len(keys0))]
-    finally:
-        worker.join()
-    if 'error' in cut:
-        raise cut['error']
+        mats = []
+        for k in keys0:
+            vals = [fp.embed[k] for fp in fps]
+            # straight off the language model (float tensors on the GPU, rows contiguous): nothing to convert -- judged in a few
+            # C-level passes over the list instead of a Python call per tensor; LayerBatch checks shapes and strides itself
+            if not (all(map(torch.is_tensor, vals)) and all(map(_IS_CUDA, vals)) and set(map(_DTYPE, vals)) <= _KEPT_DTYPES):
+                vals = [_to_device_matrix(v, keep_half=True) for v in vals]
+            mats.append(vals)
+        layers = []
+        for i in range(len(keys0)):
+            try:
+                layers.append(LayerBatch(mats[i], qdim[2 * i], qdim[2 * i + 1]))
+            except ValueError:       # (row-strided or transposed views, mixed strides: made contiguous one by one, then judged again)
+                mats[i] = [_to_device_matrix(v, keep_half=True).contiguous() for v in mats[i]]
+                layers.append(LayerBatch(mats[i], qdim[2 * i], qdim[2 * i + 1]))
+        built['keys0'], built['mats'], built['layers'] = keys0, mats, layers
+
+    cut = {'doms': reccut.domains_from_maps(maps, threshold, threads=max(1, threads), before_wait=build_tables)}
+    if 'layers' not in built:
+        build_tables()
+    keys0, mats, layers = built['keys0'], built['mats'], built['layers']
     for fp, d, n in zip(fps, cut['doms'], lens):
         if len(d) > 1:
             d.append(f'1-{n}')                                 # src/fingerprint.py:106-107

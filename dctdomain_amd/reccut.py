@@ -117,6 +117,119 @@ def top_contacts_batch(maps: Sequence[torch.Tensor], t: float, sort: bool = True
     return offs, hi, hj, hv
 
 
+def _select_on_device(maps: Sequence[torch.Tensor], t: float):
+    """``dctfp_contact_topk`` for a batch, everything left on the device: (n_res, counts, offs [host], oi, oj, ov, on [device])."""
+    n = len(maps)
+    device = maps[0].device
+    lib = _lib.load()
+    n_res = np.fromiter(map(len, maps), dtype=np.int32, count=n)
+    L64 = n_res.astype(np.int64)
+    cand = np.where(L64 >= 6, (L64 - 5) * (L64 - 4) // 2, 0)
+    counts = np.minimum(np.maximum((float(t) * L64.astype(np.float64)).astype(np.int64), 0), cand)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=offs[1:])
+    total = int(offs[-1])
+    oi = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+    oj = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+    ov = torch.empty(max(total, 1), dtype=torch.float32, device=device)
+    on = torch.zeros(n, dtype=torch.int32, device=device)
+    ptrs = np.fromiter(map(torch.Tensor.data_ptr, maps), dtype=np.uint64, count=n)
+    lds = np.fromiter(map(torch.Tensor.stride, maps, repeat(0)), dtype=np.int64, count=n)
+    lds = np.where(n_res > 1, lds, np.maximum(L64, 1))
+    ctx = _lib.get_context(device.index)
+    sp = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    _lib.check(lib.dctfp_contact_topk(ctx.handle, ptrs.ctypes.data, lds.ctypes.data, n_res.ctypes.data, n, float(t),
+                                      oi.data_ptr(), oj.data_ptr(), ov.data_ptr(), offs.ctypes.data, on.data_ptr(), sp))
+    return n_res, counts, offs, oi, oj, ov, on
+
+
+#: proteins of the last ``domains_from_maps`` / ``domains_from_contacts_gpu`` call of this thread that the GPU cutter handed back
+#: to the host library (status -1) -- tests and profiles read it
+LAST = threading.local()
+
+
+def _cut_on_device(n_res, counts, offs, oi, oj, ov, on, cut1, cut2, threads, before_wait):
+    """``dctfp_reccut`` on contacts that already sit on the device (+ the host library for what it hands back)."""
+    n = len(n_res)
+    device = oi.device
+    lib = _lib.load()
+    uniq = np.unique(n_res)
+    room = np.fromiter((lib.dctfp_reccut_room(int(v)) for v in uniq), dtype=np.int64, count=len(uniq))[np.searchsorted(uniq, n_res)]
+    enc_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(room, out=enc_off[1:])
+    enc = torch.empty(int(enc_off[-1]), dtype=torch.int32, device=device)
+    ctx = _lib.get_context(device.index)
+    stream = torch.cuda.current_stream(device)
+    _lib.check(lib.dctfp_reccut(ctx.handle, n_res.ctypes.data, n, oi.data_ptr(), oj.data_ptr(), ov.data_ptr(), offs.ctypes.data,
+                                float(cut1), float(cut2), enc.data_ptr(), enc_off.ctypes.data, C.c_void_p(stream.cuda_stream)), lib)
+    penc = _pinned('enc', torch.int32, int(enc_off[-1]))
+    penc.copy_(enc, non_blocking=True)
+    pn = None
+    if on is not None:
+        pn = _pinned('n', torch.int32, n)
+        pn.copy_(on, non_blocking=True)
+    if before_wait is not None:
+        before_wait()
+    stream.synchronize()
+    if pn is not None and not (pn.numpy() == counts).all():
+        raise RuntimeError('dctfp_contact_topk wrote a different number of contacts than dctfp_contact_count says')
+    rlib = _lib.load_reccut()
+    cap = 64 * n + 16 * int(n_res.astype(np.int64).sum())
+    buf = np.empty(cap, dtype=np.uint8)
+    out_off = np.zeros(n + 1, dtype=np.int64)
+    nd = np.zeros(n, dtype=np.int32)
+    needs = np.zeros(n, dtype=np.uint8)
+    ret = rlib.reccut_format_packed(n, penc.numpy().ctypes.data, enc_off.ctypes.data, buf.ctypes.data, cap, out_off.ctypes.data,
+                                    nd.ctypes.data, needs.ctypes.data)
+    if ret != 0:
+        raise RuntimeError(f'reccut_format_packed failed: {ret}')
+    text = buf[:int(out_off[-1])].tobytes().decode('ascii')
+    bounds = out_off.tolist()
+    doms = [text[a:b].split(';')[:-1] for a, b in zip(bounds[:-1], bounds[1:])]
+    redo = np.flatnonzero(needs)
+    LAST.host_redo = redo.tolist()
+    if len(redo):      # the host library on these proteins' own contacts (copied over now: they are few)
+        sel_off = np.zeros(len(redo) + 1, dtype=np.int64)
+        np.cumsum(counts[redo], out=sel_off[1:])
+        pick = np.concatenate([np.arange(offs[p], offs[p + 1]) for p in redo]) if sel_off[-1] else np.zeros(0, np.int64)
+        pick_t = torch.from_numpy(pick).to(device)
+        hi, hj, hv = (x[pick_t].cpu().numpy() for x in (oi, oj, ov))
+        for p, d in zip(redo.tolist(), domains_from_contacts(n_res[redo], sel_off, hi, hj, hv, cut1, cut2, threads=threads)):
+            doms[p] = d
+    return doms
+
+
+def domains_from_maps(maps: Sequence[torch.Tensor], t: float, cut1=CUT1_DEFAULT, cut2=CUT2_DEFAULT, threads: int = 1,
+                      before_wait=None) -> List[List[str]]:
+    """``Fingerprint.reccut``'s domain lists for a batch of contact maps with NOTHING but the answer leaving the GPU: the contact
+    selection (``dctfp_contact_topk``) and the domain cutter's recursion (``dctfp_reccut``: src/RecCut.cpp:150-351, one
+    workgroup per protein) run back to back on the device; what comes over is a few ints per domain, which libreccut formats
+    into the binary's strings.  Proteins the GPU cutter hands back (status -1: longer than its tables, or a step the
+    reference leaves undefined) go through the host library on their own contacts.  ``before_wait`` (a callable) runs after
+    the kernels are enqueued and before this thread waits for them -- a flush builds its embedding tables there."""
+    if len(maps) == 0:
+        return []
+    n_res, counts, offs, oi, oj, ov, on = _select_on_device(maps, t)
+    return _cut_on_device(n_res, counts, offs, oi, oj, ov, on, cut1, cut2, threads, before_wait)
+
+
+def domains_from_contacts_gpu(n_res: Sequence[int], offs, ci, cj, cv, cut1=CUT1_DEFAULT, cut2=CUT2_DEFAULT, threads: int = 1,
+                              device=None) -> List[List[str]]:
+    """``domains_from_contacts`` with the recursion on the GPU (``dctfp_reccut``): the same contact lists (host arrays, pairs
+    distinct) -> the same strings."""
+    n_res = np.ascontiguousarray(n_res, dtype=np.int32)
+    if len(n_res) == 0:
+        return []
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+    oi = torch.from_numpy(np.ascontiguousarray(ci, dtype=np.int32)).to(device)
+    oj = torch.from_numpy(np.ascontiguousarray(cj, dtype=np.int32)).to(device)
+    ov = torch.from_numpy(np.ascontiguousarray(cv, dtype=np.float32)).to(device)
+    if oi.numel() == 0:
+        oi, oj, ov = (torch.zeros(1, dtype=d, device=device) for d in (torch.int32, torch.int32, torch.float32))
+    return _cut_on_device(n_res, np.diff(offs), offs, oi, oj, ov, None, cut1, cut2, threads, None)
+
+
 def ce_text(pid: str, seq: str, ci, cj, cv) -> str:
     """The .ce file body of src/fingerprint.py:69-80."""
     slen = len(seq)

@@ -182,6 +182,25 @@ int dctfp_contact_sort(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
                        double t, int32_t* out_i, int32_t* out_j, float* out_v, const int64_t* out_offs, uint8_t* sorted,
                        void* stream);
 
+/* The domain cutter itself -- recursiveMaxCut of src/RecCut.cpp (:150-351: single and double max-cut scores over the contact graph,
+ * accept / recurse rules, the segment bookkeeping of SplitDomain / SplitDomain_2cuts :16-148), which Fingerprint.reccut reaches
+ * through a .ce text file and a subprocess (src/fingerprint.py:92-103) -- for a batch of proteins ON THE GPU, on the contacts
+ * dctfp_contact_topk left on the device: one workgroup per protein, sparse adjacency lists, the same integers and the same double
+ * expressions as the reference, so the same cuts (include/reccut.h's host library is the definition; both are held to the
+ * reference's compiled binary by the tests).
+ *   n_res, offs, out_offs : host arrays; protein p's contacts are [offs[p], offs[p+1]) of ci / cj / cv (device; pairs distinct,
+ *                           as dctfp_contact_topk writes them), weights as the .ce text carries them
+ *   out (device, or the device address of pinned host memory): protein p's result at out + out_offs[p], room out_offs[p+1] -
+ *                           out_offs[p] >= dctfp_reccut_room(n_res[p]) ints:
+ *                               out[0] = number of domains D, then per domain: n_segs, then n_segs x (first, last), 0-based residues,
+ *                           in the order the binary prints them; out[0] = -1: NOT DONE HERE -- more residues / contacts than the
+ *                           kernel's tables hold (2 048 residues; contacts + 3 L <= 12 288), a contact outside the protein or a
+ *                           non-finite value, or a step at which the reference indexes outside its segment table (undefined
+ *                           behaviour there): run reccut_predict (include/reccut.h) on that protein. */
+int dctfp_reccut(dctfp_ctx* ctx, const int32_t* n_res, int32_t n_prot, const int32_t* ci, const int32_t* cj, const float* cv,
+                 const int64_t* offs, double cut1, double cut2, int32_t* out, const int64_t* out_offs, void* stream);
+int64_t dctfp_reccut_room(int32_t n_res);
+
 /* The chunk stitcher of Embedding.embed_seq (src/embedding.py:153-192): a sequence longer than
  * maxlen is embedded in windows; per layer `run[-200:] = (run[-200:] + new[:200]) / 2` then
  * `cat(new[200:])` (:185-187), and for the contact maps combine_contacts (:123-150).  One job =

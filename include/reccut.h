@@ -43,6 +43,17 @@ int reccut_predict(int32_t n_res, const int32_t* ci, const int32_t* cj, const fl
  * Computed without the text round trip unless the value sits within 1e-5 of a rounding boundary. */
 int32_t reccut_contact_weight(float prob);
 
+/* The same weight in exact arithmetic, without the text round trip (p * 10^6 is exact in double; "%.6f" rounds that exact value
+ * half-to-even; strtod returns the double nearest to n / 10^6): what the GPU cutter (dctfp_reccut, include/dctfp.h) computes.
+ * tests/test_reccut.py holds the two against each other. */
+int32_t reccut_contact_weight_exact(float prob);
+
+/* The strings of dctfp_reccut's encoded results (include/dctfp.h: {D, then per domain n_segs, (first, last) ...} at enc +
+ * enc_off[p]), packed like reccut_predict_packed's: protein p's "1-70,180-261;71-179;" at out[out_off[p], out_off[p+1]).
+ * needs_host[p] = 1 (and an empty string) where the GPU left the protein to this library (status -1). */
+int reccut_format_packed(int64_t n_prot, const int32_t* enc, const int64_t* enc_off, char* out, int64_t out_cap, int64_t* out_off,
+                         int32_t* n_domains, uint8_t* needs_host);
+
 /* Many proteins on n_threads host threads.  Protein p uses contacts [offs[p], offs[p+1]) and writes
  * its string at out + p * out_stride.  rc[p] receives the per-protein return code. */
 int reccut_predict_batch(int64_t n_prot, const int32_t* n_res, const int64_t* offs, const int32_t* ci,

@@ -218,3 +218,91 @@ def test_contact_weight_matches_text_round_trip():
                            np.array([0, 1, 0.5, 1e-7, 5e-3, 0.995, -0.2, -1e-9, 2.0], dtype=np.float32)])
     for p in vals:
         assert lib.reccut_contact_weight(float(p)) == int(float('%.6f' % float(p)) * 100 + 0.5), float(p)
+
+
+# ------------------------------------------------------------------ the cutter's recursion on the GPU (dctfp_reccut, round 5)
+def _random_graph(rng, L):
+    """Block / interleaved contact lists as in the host library's fuzz: (ii, jj, float32 probabilities), pairs distinct."""
+    nb = int(rng.integers(1, 8))
+    bounds = np.sort(rng.choice(np.arange(1, L), size=min(nb - 1, L - 1), replace=False)) if nb > 1 else []
+    lab = np.zeros(L, int)
+    for b in bounds:
+        lab[b:] += 1
+    for _m in range(int(rng.integers(0, 3))):
+        if nb >= 3:
+            a, b = sorted(rng.choice(nb, 2, replace=False))
+            lab[lab == b] = a
+    same = lab[:, None] == lab[None, :]
+    p = rng.random((L, L)) * (same * rng.uniform(0.5, 1.0) + (~same) * rng.uniform(0.0, 0.3))
+    if rng.random() < 0.3:
+        p = np.round(p * 8) / 8      # few distinct weights: ties between cut scores
+    mask = np.triu(rng.random((L, L)) < rng.uniform(0.02, 0.3), int(rng.integers(1, 7)))
+    ii, jj = np.nonzero(mask)
+    t = int(2.6 * L)
+    if len(ii) > t:
+        order = np.argsort(-p[ii, jj], kind='stable')[:t]
+        ii, jj = ii[order], jj[order]
+    return ii.astype(np.int32), jj.astype(np.int32), p[ii, jj].astype(np.float32)
+
+
+@pytest.mark.gpu
+def test_gpu_reccut_goldens():
+    """The reference binary's domain strings (60 goldens) from the recursion on the GPU, in one batch; only what the kernel's
+    tables do not hold (L > 2 048) may come back through the host library."""
+    import torch
+    from dctdomain_amd import reccut
+    sel = [c for c in CASES if abs(c['t'] - 2.6) < 1e-12 and c['reccut_rc'] == 0]
+    maps = [torch.from_numpy(build_map(c)).cuda() for c in sel]
+    doms = reccut.domains_from_maps(maps, 2.6)
+    redone = [sel[p]['L'] for p in reccut.LAST.host_redo]
+    assert all(L > 2048 for L in redone), redone
+    for c, d in zip(sel, doms):
+        assert (d + [f"1-{c['L']}"] if len(d) > 1 else d) == c['domains'], c['id']
+    # ... and from the goldens' own contact lists (no selection kernel in front)
+    n_res, offs, ci, cj, cv = [], [0], [], [], []
+    for c in sel:
+        cmap = build_map(c)
+        i, j = ARR[f"{c['id']}/i"], ARR[f"{c['id']}/j"]
+        n_res.append(c['L']); ci.append(i); cj.append(j); cv.append(cmap[i, j]); offs.append(offs[-1] + len(i))
+    got = reccut.domains_from_contacts_gpu(n_res, offs, np.concatenate(ci), np.concatenate(cj), np.concatenate(cv))
+    assert got == doms
+
+
+@pytest.mark.gpu
+def test_gpu_reccut_fuzz_against_host_library():
+    """4 000 random graphs (blocks, interleaved blocks, tie-rich weights, contacts inside the band, L = 22 .. 700, a few up to
+    1 500) through both: identical strings; the host library itself is held to the reference's binary by the tests above."""
+    from dctdomain_amd import reccut
+    rng = np.random.default_rng(777)
+    n_multi = n_disc = n_total = 0
+    for batch in range(8):
+        n_res, offs, ci, cj, cv = [], [0], [], [], []
+        for k in range(500):
+            L = int(rng.integers(22, 700)) if k % 50 else int(rng.integers(700, 1500))
+            ii, jj, pv = _random_graph(rng, L)
+            n_res.append(L); ci.append(ii); cj.append(jj); cv.append(pv); offs.append(offs[-1] + len(ii))
+        args = (n_res, offs, np.concatenate(ci), np.concatenate(cj), np.concatenate(cv))
+        exp = reccut.domains_from_contacts(*args, threads=8)
+        got = reccut.domains_from_contacts_gpu(*args)
+        assert reccut.LAST.host_redo == [], [n_res[p] for p in reccut.LAST.host_redo]
+        for p, (e, g) in enumerate(zip(exp, got)):
+            assert e == g, (batch, p, n_res[p], e, g)
+        n_multi += sum(len(e) > 1 for e in exp)
+        n_disc += sum(any(',' in d for d in e) for e in exp)
+        n_total += len(exp)
+    assert n_total == 4000 and n_multi > 1000 and n_disc > 100
+
+
+def test_contact_weight_exact_is_the_text_round_trip():
+    """(int)(strtod("%.6f" % p) * 100 + 0.5) without the text: what dctfp_reccut's kernel computes per contact."""
+    from dctdomain_amd import _lib
+    lib = _lib.load_reccut()
+    rng = np.random.default_rng(1)
+    n = rng.integers(0, 100, 20000)
+    b = (n + 0.5) / 100
+    m = rng.integers(0, 1000000, 20000)
+    vals = np.concatenate([rng.random(20000), b + rng.normal(0, 3e-7, len(b)), b + rng.integers(-3, 4, len(b)) * 5e-8,
+                           (m + 0.5) / 1e6 + rng.integers(-2, 3, len(m)) * 1e-9, -rng.random(500),
+                           [1 / 128, 3 / 128, 5 / 256, 0.0, 1.0, 0.999999, 0.9999995, 0.5, 0.005, 0.015, 0.025, 1e-7]]).astype(np.float32)
+    for p in vals.tolist():
+        assert lib.reccut_contact_weight_exact(p) == int(float('%.6f' % p) * 100 + 0.5) == lib.reccut_contact_weight(p), p
