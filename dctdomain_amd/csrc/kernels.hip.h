@@ -2881,25 +2881,28 @@ __global__ __launch_bounds__(TH, 4) void row_select_reg_kernel(const int32_t* __
     uint32_t kmin[NMIN];
 #pragma unroll
     for (int q = 0; q < NMIN; ++q) kmin[q] = 0xffffffffu;
-    {   // All loads first, unconditionally: a load under `if (c < n)` is waited for before the next one is issued -- 40 round
-        // trips to HBM per wave.  Through a buffer descriptor that ends with the segment: one lane offset for all of them
-        // (40 clamped addresses would cost 40 more registers), a slot past the end reads 0 and is overwritten below.
+    // All loads first, unconditionally: a load under `if (c < n)` is waited for before the next one is issued -- 40 round
+    // trips to HBM per wave.  Through a buffer descriptor that ends with the segment: one lane offset for all of them
+    // (40 clamped addresses would cost 40 more registers), a slot past the end reads 0 and is overwritten below.
+    auto load_row = [&](uint32_t (&kk_)[PER], uint32_t (&cc_)[COLS ? PER : 1]) {
         const __amdgpu_buffer_rsrc_t vb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(v), 0, n * 4, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < PER; ++j) key[j] = __builtin_amdgcn_raw_buffer_load_b32(vb, tid * 4, j * TH * 4, DCTFP_STREAM_AUX);
+        for (int j = 0; j < PER; ++j) kk_[j] = __builtin_amdgcn_raw_buffer_load_b32(vb, tid * 4, j * TH * 4, DCTFP_STREAM_AUX);
         if (COLS) {
             const __amdgpu_buffer_rsrc_t cb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(cs), 0, n * 4, 0x00020000);
 #pragma unroll
-            for (int j = 0; j < PER; ++j) col[j] = __builtin_amdgcn_raw_buffer_load_b32(cb, tid * 4, j * TH * 4, 0);
+            for (int j = 0; j < PER; ++j) cc_[j] = __builtin_amdgcn_raw_buffer_load_b32(cb, tid * 4, j * TH * 4, 0);
         }
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const bool have = j * TH + tid < n;
-            key[j] = have ? key[j] ^ 0x80000000u : 0xffffffffu;
-            if (COLS) col[j] = have ? col[j] : 0xffffffffu;
-            kmin[j / SHARE] = min(kmin[j / SHARE], key[j]);
+            kk_[j] = have ? kk_[j] ^ 0x80000000u : 0xffffffffu;
+            if (COLS) cc_[j] = have ? cc_[j] : 0xffffffffu;
         }
-    }
+    };
+    load_row(key, col);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) kmin[j / SHARE] = min(kmin[j / SHARE], key[j]);
     const int my_n = tid < n ? (n - tid + TH - 1) / TH : 0;  // my entries: j < my_n
     auto col_of = [&](int j) { return COLS ? col[j] : (uint32_t)(j * TH + tid); };   // (segment-local, or as it came)
     const uint32_t col_hi = COLS ? 0x7fffffffu : (uint32_t)(n - 1);
@@ -2910,6 +2913,10 @@ __global__ __launch_bounds__(TH, 4) void row_select_reg_kernel(const int32_t* __
 #pragma unroll
     for (int q = 0; q < NMIN; ++q) s_min[q * TH + tid] = kmin[q];
     __syncthreads();
+#if defined(DCTFP_RSEL_STOP) && DCTFP_RSEL_STOP == 1
+    if (tid == 0) ov[0] = (int32_t)s_min[5];
+    return;
+#endif
     if (tid < 64) {   // 1.: the kk-th smallest of the 1024 minima.  With one minimum per thread at least kk of them are real (kk <=
         // min(n, 1024)); with two, a short segment may fill fewer than kk shares: the bound is then 0xffffffff -- an upper bound
         // all the same, and what follows tells real entries of that value from empty slots.
@@ -2939,45 +2946,68 @@ __global__ __launch_bounds__(TH, 4) void row_select_reg_kernel(const int32_t* __
     }
     __syncthreads();
     const uint32_t bound = sh.bound, row_min = sh.row_min;
+#if defined(DCTFP_RSEL_STOP) && DCTFP_RSEL_STOP == 2
+    if (tid == 0) ov[0] = (int32_t)(bound + key[3]);
+    return;
+#endif
     int step = 0;
-    uint32_t below = 0;   // 2.: (empty slots hold 0xffffffff: never below)
+    // 2.: the entries below the bound, counted and moved to LDS in ONE pass over the registers: every wave appends to a part of the
+    // buffer of its own (kSelectCap / waves slots; its fill count is a wave-uniform register: no LDS counter, no atomics, no wait
+    // between two registers) -- counting them first (a compare, a lane mask, popcount and add per register) and compacting them
+    // through one shared LDS counter afterwards was 0.2 of the kernel's 0.29 ms, more than its read of the row.  (Empty slots hold
+    // 0xffffffff: never below.)
+    constexpr int NWV = TH / 64, WCAP = kSelectCap / NWV;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t w_fill = 0;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) below += lane_votes(key[j] < bound);
-    if (lane == 0) atomicAdd(&sh.cnt[step], below);
-    __syncthreads();
-    below = sh.cnt[step];
-    ++step;
-    if (below < kk) {                          // T = bound
-        bisect_emit<PER>(key, col_of, [&](int j) { return j < my_n; }, bound, bound, below, col_hi, kk, sh, step, emit);
-    } else if (below <= (uint32_t)kSelectCap) {   // 3.: T < bound, among the `below` entries under the bound
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const bool take = key[j] < bound;
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(take);
-            if (mask != 0) {   // (wave-uniform)
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&sh.fill, (uint32_t)__builtin_popcountll(mask));
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (take) {
-                    s_ckey[base + rank] = key[j];
-                    s_ccol[base + rank] = col_of(j);
-                }
+    for (int j = 0; j < PER; ++j) {
+        const bool take = key[j] < bound;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(take);
+        if (mask != 0) {   // (wave-uniform)
+            const uint32_t at = w_fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (take && at < (uint32_t)WCAP) {
+                s_ckey[wave * WCAP + at] = key[j];
+                s_ccol[wave * WCAP + at] = col_of(j);
             }
+            w_fill += (uint32_t)__builtin_popcountll(mask);
         }
-        __syncthreads();
+    }
+    if (lane == 0) sh.wave_cnt[wave] = w_fill;
+    __syncthreads();
+    uint32_t below = 0;
+    bool fits = true;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+        below += sh.wave_cnt[w];
+        fits = fits && sh.wave_cnt[w] <= (uint32_t)WCAP;
+    }
+#if defined(DCTFP_RSEL_STOP) && DCTFP_RSEL_STOP == 3
+    if (tid == 0) ov[0] = (int32_t)below;
+    return;
+#endif
+    if (below >= kk && fits) {                 // 3.: T < bound, among the `below` entries under the bound
         constexpr int E = kSelectCap / TH;
         uint32_t ck[E], cc[E];
+        bool have[E];
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             const uint32_t e = (uint32_t)(i * TH + tid);
-            ck[i] = e < below ? s_ckey[e] : 0xffffffffu;
-            cc[i] = e < below ? s_ccol[e] : 0xffffffffu;
+            have[i] = (e % (uint32_t)WCAP) < sh.wave_cnt[e / (uint32_t)WCAP];
+            ck[i] = have[i] ? s_ckey[e] : 0xffffffffu;
+            cc[i] = have[i] ? s_ccol[e] : 0xffffffffu;
         }
-        bisect_emit<E>(ck, [&](int i) { return cc[i]; }, [&](int i) { return (uint32_t)(i * TH + tid) < below; }, row_min, bound - 1u, 0u,
+        bisect_emit<E>(ck, [&](int i) { return cc[i]; }, [&](int i) { return have[i]; }, row_min, bound - 1u, 0u,
                        col_hi, kk, sh, step, emit);
-    } else {                                   // a row of few distinct values
-        bisect_emit<PER>(key, col_of, [&](int j) { return j < my_n; }, row_min, bound - 1u, 0u, col_hi, kk, sh, step, emit);
+    } else {
+        // Rare: fewer than kk entries below the bound (T = the bound itself), or a row of few distinct values whose entries below
+        // the bound do not fit the buffer.  The row is READ AGAIN for it: held in its 80 registers across the selection above,
+        // it cost that path 40 spilled registers per lane.
+        uint32_t key2[PER];
+        uint32_t col2[COLS ? PER : 1];
+        load_row(key2, col2);
+        auto col_of2 = [&](int j) { return COLS ? col2[j] : (uint32_t)(j * TH + tid); };
+        if (below < kk) bisect_emit<PER>(key2, col_of2, [&](int j) { return j < my_n; }, bound, bound, below, col_hi, kk, sh, step, emit);
+        else bisect_emit<PER>(key2, col_of2, [&](int j) { return j < my_n; }, row_min, bound - 1u, 0u, col_hi, kk, sh, step, emit);
     }
     for (uint32_t pos = kk + (uint32_t)tid; pos < (uint32_t)k; pos += TH) {   // a segment shorter than k: candidates that lose every tie
         ov[pos] = 0x7fffffff;
