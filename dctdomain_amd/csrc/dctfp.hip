@@ -596,6 +596,7 @@ int dctfp_destroy(dctfp_ctx* ctx) try {
     ctx->ws.release();
     ctx->scratch.release();
     ctx->split_ws.release();
+    ctx->cut_ws.release();
     for (auto& kv : ctx->st_cache) {
         (void)hipFree(kv.second.dev);
         if (kv.second.frag) (void)hipFree(kv.second.frag);

@@ -69,7 +69,7 @@ static int other_entry_points(dctfp_ctx* ctx, std::mt19937_64& rng, int rounds, 
     auto ok_or_expected = [&](int rc, const char* what) {
         ++*n_calls;
         if (rc == DCTFP_OK) return true;
-        if (rc == DCTFP_ERR_NOMEM || rc == DCTFP_ERR_SHAPE || rc == DCTFP_ERR_INVALID || rc == DCTFP_ERR_LIMIT) { ++*n_expected; return true; }
+        if (rc == DCTFP_ERR_NOMEM || rc == DCTFP_ERR_SHAPE || rc == DCTFP_ERR_INVALID || rc == DCTFP_ERR_LIMIT || rc == DCTFP_ERR_UNSUPPORTED) { ++*n_expected; return true; }
         fprintf(stderr, "%s -> %d: %s\n", what, rc, dctfp_last_error());
         return false;
     };
@@ -144,6 +144,96 @@ static int other_entry_points(dctfp_ctx* ctx, std::mt19937_64& rng, int rounds, 
             rc = dctfp_contact_sort(ctx, ptrs.data(), ld.data(), n_res.data(), n_prot, t, oi.data(), oj.data(), ov.data(), offs.data(), sorted.data(), nullptr);
             g_fail_after = -1;
             if (!ok_or_expected(rc, "dctfp_contact_sort")) return 1;
+            // ---- the domain cutter on the selected contacts: job table, scratch sizes, the three size classes on their streams
+            std::vector<int64_t> enc_off(n_prot + 1, 0);
+            for (int p = 0; p < n_prot; ++p) enc_off[p + 1] = enc_off[p] + dctfp_reccut_room(n_res[p]) - (uni(0, 30) == 0 ? 100 : 0);   // (sometimes no room: an error)
+            std::vector<int32_t> enc((size_t)std::max<int64_t>(enc_off[n_prot], 1));
+            if (starve) g_fail_after = uni(0, 8);
+            rc = enc_off[n_prot] >= 0 ? dctfp_reccut(ctx, n_res.data(), n_prot, oi.data(), oj.data(), ov.data(), offs.data(), 0.08, 0.07, enc.data(), enc_off.data(), nullptr)
+                                      : DCTFP_OK;
+            g_fail_after = -1;
+            if (!ok_or_expected(rc, "dctfp_reccut")) return 1;
+        }
+        // ---- Fingerprint.quantize over windows: the geometry of every piece (one window's rows / the rows two windows share), the
+        // refusals, the walk kernel's two-source builds (the stub touches both rows of every shared piece)
+        {
+            const int D = (int[]){640, 1280, 2560, 96, 1280}[uni(0, 4)];
+            const int dtype = uni(0, 7) == 0 ? DCTFP_F16 : DCTFP_F32;
+            const size_t esz = dtype == DCTFP_F32 ? 4 : 2;
+            const int overlap = (int[]){200, 200, 30}[uni(0, 2)], maxlen = overlap == 200 ? (int[]){500, 500, 400, 300}[uni(0, 3)] : uni(60, 90);
+            const int n_seq = uni(0, 3) == 0 ? uni(1, 6) : uni(130, 220);
+            const int n_layers = uni(1, 2);
+            const int64_t ld = D + (uni(0, 4) == 0 ? 8 : 0);
+            std::vector<int64_t> seq_win(n_seq + 1, 0), rows_of(n_seq);
+            std::vector<int32_t> win_rows;
+            std::vector<dctfp_piece> pieces;
+            int32_t n_domains = 0;
+            for (int s = 0; s < n_seq; ++s) {
+                const int L = uni(0, 40) == 0 ? uni(1, overlap) : uni(3, 6 * maxlen);
+                int n = 0;
+                if (L <= maxlen) {
+                    win_rows.push_back(L);
+                    n = 1;
+                } else {
+                    for (int i = 0; i < L; i += maxlen - overlap) {
+                        const int len = std::min(maxlen, L - i);
+                        if (len > overlap) { win_rows.push_back(len); ++n; }
+                    }
+                }
+                if (uni(0, 60) == 0 && n > 1) win_rows.back() = uni(1, overlap);          // not longer than the overlap: ERR_SHAPE
+                seq_win[s + 1] = seq_win[s] + n;
+            }
+            int rc = dctfp_stitch_sizes(win_rows.data(), seq_win.data(), n_seq, overlap, 0, rows_of.data());
+            if (!ok_or_expected(rc, "dctfp_stitch_sizes (windows)")) return 1;
+            const bool geometry_ok = rc == DCTFP_OK;
+            for (int s = 0; s < n_seq; ++s) {
+                const int64_t L = geometry_ok ? rows_of[s] : 50;
+                auto add = [&](int64_t start, int64_t rows, int32_t dom) { pieces.push_back({start, (int32_t)rows, dom, s, 0}); };
+                const int kind = uni(0, 9);
+                if (kind < 5 || L < 12) add(0, L, n_domains++);
+                else if (kind < 9) {                                                    // parts tiling the sequence (cuts anywhere) + the whole
+                    const int k = (int)std::min<int64_t>(uni(2, 6), L / 4);
+                    std::vector<int64_t> cut{0};
+                    for (int i = 1; i < k; ++i) cut.push_back(cut.back() + std::max<int64_t>(3, (L - cut.back()) / (k - i + 1) + uni(-1, 1)));
+                    cut.push_back(L);
+                    bool ok = true;
+                    for (size_t i = 1; i < cut.size(); ++i) ok = ok && cut[i] - cut[i - 1] >= 3;
+                    if (!ok) { add(0, L, n_domains++); continue; }
+                    for (int i = 0; i < k; ++i) add(cut[i], cut[i + 1] - cut[i], n_domains++);
+                    add(0, L, n_domains++);
+                } else {
+                    const int64_t a = uni(0, (int)(L / 2)), b = std::min<int64_t>(L + (uni(0, 20) == 0 ? 5 : 0), a + uni(3, (int)L));   // (sometimes past the end: ERR_INVALID)
+                    add(a, b - a, n_domains++);
+                }
+            }
+            const size_t n_win = win_rows.size();
+            std::vector<std::vector<char*>> data(n_layers, std::vector<char*>(n_win));
+            std::vector<std::vector<const void*>> wp(n_layers, std::vector<const void*>(n_win));
+            for (int l = 0; l < n_layers; ++l)
+                for (size_t w = 0; w < n_win; ++w) {
+                    const size_t bytes = ((size_t)std::max(win_rows[w] - 1, 0) * ld + D) * esz;
+                    data[l][w] = (char*)aligned_alloc(64, (bytes + 63) / 64 * 64);
+                    wp[l][w] = data[l][w];
+                }
+            std::vector<dctfp_layer> layers(n_layers);
+            int32_t off = 0;
+            static const int wq[][2] = {{3, 80}, {3, 80}, {3, 80}, {5, 44}};
+            const int* q = wq[uni(0, 3)];
+            for (int l = 0; l < n_layers; ++l) {
+                layers[l] = {wp[l].data(), ld, D, dtype, q[0], q[1], off, 0};
+                off += q[0] * q[1];
+            }
+            std::vector<int8_t> out((size_t)std::max(n_domains, 1) * off);
+            const int path = uni(0, 2);
+            if (dctfp_set_option(ctx, "path", path) != DCTFP_OK) return 1;
+            if (starve) g_fail_after = uni(0, 30);
+            rc = dctfp_quantize_windows(ctx, layers.data(), n_layers, n_seq, seq_win.data(), win_rows.data(), overlap, pieces.data(), (int64_t)pieces.size(),
+                                        n_domains, out.data(), off, nullptr);
+            g_fail_after = -1;
+            if (dctfp_set_option(ctx, "path", 0) != DCTFP_OK) return 1;
+            for (int l = 0; l < n_layers; ++l)
+                for (size_t w = 0; w < n_win; ++w) free(data[l][w]);
+            if (!ok_or_expected(rc, "dctfp_quantize_windows")) return 1;
         }
         // ---- window stitching: geometry, the one-launch form, the sequential form, malformed windows
         {
