@@ -1840,6 +1840,40 @@ int dctfp_quantize_windows(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_
                          nullptr, src.data(), n_win);
 } DCTFP_GUARD("dctfp_quantize_windows")
 
+int dctfp_quantize_one(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, int64_t n_rows, const char* dom_text,
+                       int64_t text_len, int32_t n_strings, int8_t* out, int64_t out_rows, int64_t out_stride, int32_t* str_row,
+                       uint8_t* str_changed, char* key_text, int64_t key_cap, int64_t* key_len, int64_t* n_domains,
+                       int64_t* n_other, int32_t* degenerate_seen, void* stream_v) try {
+    if (!ctx || !dom_text || !str_row || !str_changed || !key_len || !n_domains || !n_other)
+        return fail(DCTFP_ERR_INVALID, "dctfp_quantize_one: NULL argument");
+    if (n_strings < 0 || n_rows < 0 || text_len < 0) return fail(DCTFP_ERR_INVALID, "dctfp_quantize_one: negative size");
+    *n_domains = *n_other = *key_len = 0;
+    if (degenerate_seen) *degenerate_seen = 0;
+    // the domain strings of this protein -> pieces (the reference's get_doms clean-up, src/fingerprint.py:163-169)
+    int64_t commas = 0;
+    for (int64_t i = 0; i < text_len; ++i) commas += dom_text[i] == ',';
+    std::vector<dctfp_piece> pieces((size_t)(n_strings + commas + 1));
+    std::vector<int64_t> str_len((size_t)std::max(n_strings, 1));
+    int64_t n_pieces = 0;
+    const int32_t count = n_strings;
+    int rc = dctfp_build_pieces(dom_text, text_len, &count, &n_rows, 1, pieces.data(), (int64_t)pieces.size(), &n_pieces, str_row, str_len.data(),
+                                str_changed, key_text, key_cap, key_len, n_domains, n_other);
+    if (rc) return rc;
+    if (*n_other > 0 || *n_domains == 0 || n_layers == 0) return DCTFP_OK;   // (strings for the caller's own parser / nothing to do)
+    if (*n_domains > out_rows) return fail(DCTFP_ERR_LIMIT, "dctfp_quantize_one: %lld domains, room for %lld", (long long)*n_domains, (long long)out_rows);
+    hipStream_t stream = (hipStream_t)stream_v;
+    {
+        // (the constant-channel flag is the context's: what an earlier caller left unread is not about THIS protein)
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        if (ctx->flag_host) __atomic_store_n(ctx->flag_host, 0u, __ATOMIC_RELEASE);
+    }
+    rc = dctfp_quantize(ctx, layers, n_layers, 1, &n_rows, pieces.data(), n_pieces, *n_domains, out, out_stride, stream_v);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (degenerate_seen && ctx->flag_host) *degenerate_seen = (int32_t)__atomic_exchange_n(ctx->flag_host, 0u, __ATOMIC_ACQ_REL);
+    return DCTFP_OK;
+} DCTFP_GUARD("dctfp_quantize_one")
+
 int dctfp_idct_quant(dctfp_ctx* ctx, const void* vec, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
                      int32_t num, double* scaled_out, double* coef_out, void* stream_v) try {
     if (!ctx || !vec) return fail(DCTFP_ERR_INVALID, "dctfp_idct_quant: NULL argument");

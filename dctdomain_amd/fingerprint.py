@@ -200,6 +200,8 @@ class Fingerprint:
                 device = e.device
                 break
         mats = [_to_device_matrix(e, device, keep_half=True) for e in embeds]
+        if mats and self._quantize_one(mats, qdim):
+            return
 
         # layers are grouped while they share the row count (one piece table per group); every group is
         # enqueued first, the results land in ONE pinned buffer and are read after one synchronisation.
@@ -246,6 +248,96 @@ class Fingerprint:
             self.quants[key] = np.concatenate(parts).astype(np.int64) if len(parts) > 1 or parts[0].dtype != np.int64 \
                 else parts[0]
         self.domains = list(self.quants.keys())
+
+
+    def _quantize_one(self, mats, qdim) -> bool:
+        """The common shape of a call -- every layer the same rows on one GPU, plain ``b-e[,b-e]`` domain strings -- through ONE
+        foreign call (``dctfp_quantize_one``: strings -> pieces -> kernels -> wait; include/dctfp.h).  False: not that shape,
+        nothing was launched, the general path below takes the call."""
+        k, doms = len(mats), self.domains
+        st = _ONE
+        if k > st.MAX_LAYERS or len(doms) > st.MAX_STRINGS or not doms:
+            return False
+        t0 = mats[0]
+        rows, dev = t0.shape[0], t0.device
+        for t in mats:
+            if t.shape[0] != rows or t.device != dev:
+                return False
+        try:
+            text = '\n'.join(doms).encode('ascii')
+        except (UnicodeEncodeError, TypeError):
+            return False
+        if len(text) + len(doms) + 1 > st.KEY_CAP:
+            return False
+        arr, ptrs = st.arr, st.ptrs
+        width = 0
+        for i, t in enumerate(mats):
+            ptrs[i] = t.data_ptr()
+            a = arr[i]
+            a.ld = t.stride(0) if rows > 1 else t.shape[1]
+            a.n_cols = t.shape[1]
+            a.dtype = _DTYPE_CODE[t.dtype]
+            a.n_keep = n = int(qdim[2 * i])
+            a.m_keep = m = int(qdim[2 * i + 1])
+            a.out_offset = width
+            width += n * m
+        n_str = len(doms)
+        buf, off, out_ptr = _result_slot(n_str * width)
+        ctx = _lib.get_context(dev.index if dev.index is not None else torch.cuda.current_device())
+        rc = ctx._lib.dctfp_quantize_one(ctx.handle, arr, k, rows, text, len(text), n_str, out_ptr, n_str, width, st.str_row_p, st.changed_p,
+                                        st.key_p, st.KEY_CAP, st.key_len_p, st.n_dom_p, st.n_other_p, st.flag_p, _raw_stream(dev))
+        _RESULTS.used = 0
+        if rc != 0:
+            _lib.check(rc, ctx._lib)          # ValueError where the reference's reshape fails -- before quants is touched
+        if st.n_other.value:
+            return False                      # (a string for Python's own int() / split: the general path)
+        nd = st.n_dom.value
+        if st.flag.value:
+            warn_constant_channel([self.pid])
+        if nd:
+            host = buf[off:off + nd * width].reshape(nd, width)
+            changed = st.changed[:n_str]
+            cleaned = iter(st.key_buf.raw[:st.key_len.value].decode('ascii').split('\n')) if st.key_len.value else None
+            keys = []
+            for i in range(n_str):             # (every string with a piece removed has its cleaned key in key_text, kept or not)
+                key = next(cleaned) if changed[i] == 1 else doms[i]
+                if st.str_row[i] >= 0:
+                    keys.append(key)
+            if not self.quants and len(set(keys)) == nd:
+                host64 = host.astype(np.int64)             # a row already is layer 0's block, layer 1's block, ... (:184-196)
+                self.quants = dict(zip(keys, host64))
+            else:                                          # quants already holds entries / a key twice: extended layer by layer, as there
+                held = {key: [np.asarray(v)] for key, v in self.quants.items()}
+                o = 0
+                for i in range(k):
+                    nm = int(qdim[2 * i]) * int(qdim[2 * i + 1])
+                    for r, key in enumerate(keys):
+                        held.setdefault(key, []).append(host[r, o:o + nm])
+                    o += nm
+                for key, parts in held.items():
+                    self.quants[key] = np.concatenate(parts).astype(np.int64) if len(parts) > 1 or parts[0].dtype != np.int64 else parts[0]
+        self.domains = list(self.quants.keys())
+        return True
+
+
+class _OneCall(threading.local):
+    """Per thread: the argument blocks of ``dctfp_quantize_one`` (filled in place call after call)."""
+    MAX_LAYERS, MAX_STRINGS, KEY_CAP = 8, 64, 8192
+
+    def __init__(self):
+        self.arr = (_lib.Layer * self.MAX_LAYERS)()
+        self.ptrs = (C.c_void_p * self.MAX_LAYERS)()
+        for i in range(self.MAX_LAYERS):
+            self.arr[i].seq_data = C.cast(C.byref(self.ptrs, i * C.sizeof(C.c_void_p)), C.POINTER(C.c_void_p))
+        self.str_row = (C.c_int32 * self.MAX_STRINGS)()
+        self.changed = (C.c_uint8 * self.MAX_STRINGS)()
+        self.key_buf = C.create_string_buffer(self.KEY_CAP)
+        self.key_len, self.n_dom, self.n_other, self.flag = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        self.str_row_p, self.changed_p, self.key_p = C.addressof(self.str_row), C.addressof(self.changed), C.addressof(self.key_buf)
+        self.key_len_p, self.n_dom_p, self.n_other_p, self.flag_p = (C.addressof(x) for x in (self.key_len, self.n_dom, self.n_other, self.flag))
+
+
+_ONE = _OneCall()
 
 
 # scratch of the one-protein-per-call path: a pinned host buffer the kernels write their int8 results into directly

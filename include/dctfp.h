@@ -140,6 +140,19 @@ int dctfp_quantize_windows(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_
                            const int32_t* win_rows, int32_t overlap, const dctfp_piece* pieces, int64_t n_pieces,
                            int64_t n_domains, int8_t* out, int64_t out_stride, void* stream);
 
+/* Fingerprint.quantize for ONE protein -- the reference's own calling pattern (src/make_db.py:29-30 inside a process pool) -- in
+ * one call: the protein's domain strings ('\n'-separated, as for dctfp_build_pieces) are cleaned and turned into pieces, the
+ * kernels are enqueued, and the call returns when the int8 blocks have arrived in `out` (the device address of a pinned host
+ * buffer: dctfp_host_device_pointer; or device memory).  layers[l].seq_data points at ONE device pointer (the layer's matrix of
+ * n_rows rows).  str_row / str_changed / key_text / key_len / n_other as in dctfp_build_pieces (n_other > 0: a string this
+ * parser leaves to the caller's own -- nothing was launched); *degenerate_seen = 1 when a kernel of THIS call met an exactly
+ * constant channel (see "degenerate_seen").  A binding that calls dctfp_build_pieces, dctfp_quantize and
+ * dctfp_stream_synchronize itself pays three foreign calls and their argument marshalling per protein. */
+int dctfp_quantize_one(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, int64_t n_rows, const char* dom_text,
+                       int64_t text_len, int32_t n_strings, int8_t* out, int64_t out_rows, int64_t out_stride, int32_t* str_row,
+                       uint8_t* str_changed, char* key_text, int64_t key_cap, int64_t* key_len, int64_t* n_domains,
+                       int64_t* n_other, int32_t* degenerate_seen, void* stream);
+
 /* Fingerprint.idct_quant(vec, num) for a (n_rows, n_cols) device matrix
  * (src/fingerprint.py:126-142): DCT-II (ortho) along the rows, keep `num`, inverse DCT of
  * length `num`, min-max scale of every column over its `num` values.
