@@ -10,7 +10,7 @@ rm -rf "$OUT"   # (results of an earlier run would be averaged into the summary)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $REPO/bench.py --cpu-seconds 0 --parity-sample 0 $*"
+BENCH="python3 $REPO/bench.py --cpu-seconds 0 --parity-sample 0 --workloads none $*"
 echo "== kernel trace + stats" | tee "$OUT/log.txt"
 # (the bench's own step count and warm-up: what `--stats` and the steady-state summary see is then the line's timed region)
 export PROF_WARMUP=3
