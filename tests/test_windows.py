@@ -229,12 +229,14 @@ def test_windows_calls_the_fused_path_refuses(dd):
         assert torch.equal(call(fallback=False), got) and ctx.get_option('last_path') == 2
     finally:
         ctx.set_option('path', 0)
-    # (2) three windows meet in one row: maxlen 300 (windows every 100 residues)
-    layers, win_rows, counts, table, call = run([650, 901] * 70, 300, 1280)
+    # (2) three windows meet in one row: maxlen 300 (windows every 100 residues) -- the reference class's goldens of that maxlen
+    gold300 = [c['L'] for c in STITCH_CASES if c['maxlen'] == 300]
+    assert sorted(gold300) == [301, 450, 650]
+    layers, win_rows, counts, table, call = run(gold300 * 47, 300, 1280)
     with pytest.raises(_lib.DctfpError) as e:
         call(fallback=False)
     assert e.value.code == _lib.DCTFP_ERR_UNSUPPORTED and 'three windows' in e.value.msg
-    _check_against_oracle(torch, layers, win_rows, counts, [[f'1-{int(L)}'] for L in table.seq_rows], call(), table, [0, 1])
+    _check_against_oracle(torch, layers, win_rows, counts, [[f'1-{int(L)}'] for L in table.seq_rows], call(), table, [0, 1, 2])
     # (3) other kept sizes (PROST's [5, 44]) and a width the kernel does not take
     for D, qdim in ((1280, (5, 44)), (96, (3, 80))):
         layers, win_rows, counts, table, call = run([650, 901] * 70, 500, D, qdim=qdim)
