@@ -1966,8 +1966,20 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
     HIP_TRY(hipSetDevice(ctx->device));
     // long proteins (a million candidate pairs and more; a quarter of that when the call is too small to fill the chip
     // with one workgroup per protein) are spread over many workgroups, the others get one each
-    const int64_t kLongPairs = n_prot <= 32 ? (int64_t)1 << 18 : (int64_t)1 << 20;
+    // (round 5: a quarter of a million pairs whatever the size of the call -- L >= 730.  Up to a million pairs such a protein used
+    //  to get one workgroup: the one-read kernel's sample misjudges long stitched maps now and then (their top contacts sit in a
+    //  narrow band of a mostly empty triangle), the two-read kernel's thread minima bound them loosely near the top of its k
+    //  ranges, and what both hand back met the radix select on ONE workgroup -- 4.5 ms for a 1 100-residue protein, with the whole
+    //  flush waiting for it.  Spread over stripes it is 6 reads by many workgroups.)
+    const int64_t kLongPairs = (int64_t)1 << 18;
     constexpr int64_t kStripePairs = (int64_t)1 << 17;
+    // (... and whatever the one-read kernel does not take -- k > 3 000: L > 1 153 at t = 2.6 -- with half a million pairs or more:
+    //  behind it such a protein met the two-read kernel, whose candidates overflow on banded maps, and then the radix select on
+    //  ONE workgroup: 4.5 ms for a 1 300-residue protein, the whole flush waiting for it)
+    auto is_long = [&](int64_t L, int64_t cand) {
+        const int64_t k = dctfp_contact_count((int32_t)L, t);
+        return k > 0 && (cand >= kLongPairs || (k > 3000 && cand >= ((int64_t)1 << 19)));
+    };
     std::vector<int32_t> order((size_t)n_prot);
     int32_t n_short = 0, n_long = 0;
     int64_t n_stripes = 0;
@@ -1976,7 +1988,7 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
         if (L < 0 || (L > 0 && (!maps[p] || ld[p] < L)))
             return fail(DCTFP_ERR_INVALID, "dctfp_contact_topk: protein %d: bad map", p);
         const int64_t cand = L >= 6 ? (L - 5) * (L - 4) / 2 : 0;
-        if (cand >= kLongPairs && dctfp_contact_count((int32_t)L, t) > 0) {
+        if (is_long(L, cand)) {
             ++n_long;
             n_stripes += std::min<int64_t>(512, (cand + kStripePairs - 1) / kStripePairs);
         } else {
@@ -1988,7 +2000,7 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
         for (int32_t p = 0; p < n_prot; ++p) {
             const int64_t L = n_res[p];
             const int64_t cand = L >= 6 ? (L - 5) * (L - 4) / 2 : 0;
-            if (cand >= kLongPairs && dctfp_contact_count((int32_t)L, t) > 0) order[b++] = p;
+            if (is_long(L, cand)) order[b++] = p;
             else order[a++] = p;
         }
     }

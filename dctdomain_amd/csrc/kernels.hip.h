@@ -3250,8 +3250,9 @@ struct TopkSlots {   // the (row, chunk) sequence of one wave; everything here i
 
 template <bool VEC4, int NW>
 __device__ inline void topk1_run(const TopkJob& job, SelectSharedT<NW>& sh, uint32_t* __restrict__ s_key, uint32_t* __restrict__ s_ij,
-                                 int32_t* __restrict__ out_i, int32_t* __restrict__ out_j, float* __restrict__ out_v,
-                                 int32_t* __restrict__ out_n) {
+                                 uint16_t* __restrict__ s_rowt, uint32_t* __restrict__ s_rowp, int32_t* __restrict__ out_i,
+                                 int32_t* __restrict__ out_j, float* __restrict__ out_v, int32_t* __restrict__ out_n) {
+    constexpr int kRowTies = NW == 8 ? 576 : 1216;   // rows whose ties at the bound are counted (k <= 1 400 -> L <= 538; k <= 3 000 -> L <= 1 153)
     constexpr int W = VEC4 ? 4 : 1, NS = 4;   // entries per lane and load; sample loads per lane
     constexpr int WCAP = 512;                // candidates a wave may keep (its own part of the LDS buffer: no atomics)
     constexpr int TH = NW * 64;
@@ -3360,11 +3361,23 @@ __device__ inline void topk1_run(const TopkJob& job, SelectSharedT<NW>& sh, uint
     if (tid == 0) out_n[job.orig] = (int)bound;
     return;
 #endif
-    // ---- 2. keys up to the bound -> this wave's part of the LDS buffer: the sample from its registers, the rest of the triangle
-    // as it streams by.  The stream tests the VALUE against the bound's value (one compare: not below it -- NaNs pass and are
-    // judged by their key like everything that passes); key, validity and position only for what passed.
+    // ---- 2. keys BELOW the bound -> this wave's part of the LDS buffer: the sample from its registers, the rest of the triangle
+    // as it streams by.  The stream tests the VALUE against the bound's value (one compare: above it, or not comparable -- NaNs
+    // pass and are judged by their key like everything that passes); key, validity and position only for what passed.
+    // Entries EQUAL to the bound's value are only counted, per row (a row belongs to one wave: no atomics): a contact map with
+    // plateaus -- probabilities out of a half-precision model, quantised maps -- has thousands of them, they would overflow
+    // any buffer, and which of them belong to the answer is decided by position alone (step 4).
     const uint32_t tkey = ~bound;   // topk_key of the bound
     const float thr = __uint_as_float((tkey & 0x80000000u) ? (tkey & 0x7fffffffu) : ~tkey);
+    // (only where the sample says the map has them: four or more of its 16 384 keys equal to the bound -- a map of real-valued
+    //  probabilities has one, the bound itself, and keeps the cheaper test: one compare and one lane mask per register)
+    uint32_t ties_s = 0;
+#pragma unroll
+    for (int q = 0; q < NS * W; ++q) ties_s += lane_votes(((s_valid >> q) & 1u) && sk[q] == bound);
+    if (lane == 0) atomicAdd(&sh.cnt[kSelectCounters - 1], ties_s);
+    for (int q = tid; q < kRowTies; q += TH) s_rowt[q] = 0;
+    __syncthreads();
+    const bool count_ties = !whole && L <= kRowTies && sh.cnt[kSelectCounters - 1] >= 4u;
     uint32_t* __restrict__ wk = s_key + wave * WCAP;
     uint32_t* __restrict__ wij = s_ij + wave * WCAP;
     uint32_t w_fill = 0;   // (wave-uniform)
@@ -3377,15 +3390,25 @@ __device__ inline void topk1_run(const TopkJob& job, SelectSharedT<NW>& sh, uint
         }
         w_fill += (uint32_t)__builtin_popcountll(mask);
     };
+    auto offer = [&](float x, auto valid_of, int i, int j) {   // (`i` wave-uniform; validity only asked for what passes the value test)
+        if (__builtin_amdgcn_ballot_w64(!(x < thr)) == 0) return;   // (two thirds of a map's registers: nobody in the wave)
+        const bool valid = valid_of();
+        if (count_ties) {
+            const bool above = valid && !(x <= thr);
+            if (__builtin_amdgcn_ballot_w64(above) != 0) keep(__float_as_uint(x), above, i, j);
+            const unsigned long long eq = __builtin_amdgcn_ballot_w64(valid && x == thr);
+            if (eq != 0 && lane == 0) s_rowt[i] = (uint16_t)(s_rowt[i] + (uint32_t)__builtin_popcountll(eq));
+        } else {
+            const bool take = valid && !(x < thr);
+            if (__builtin_amdgcn_ballot_w64(take) != 0) keep(__float_as_uint(x), take, i, j);
+        }
+    };
 #pragma unroll
     for (int u = 0; u < NS; ++u)
 #pragma unroll
-        for (int e = 0; e < W; ++e) {
-            const bool take = ((s_valid >> (u * W + e)) & 1u) && sk[u * W + e] <= bound;
-            if (__builtin_amdgcn_ballot_w64(take) != 0) keep(__float_as_uint(elem(sv[u], e)), take, s_row[u], s_c0[u] + W * lane + e);
-        }
+        for (int e = 0; e < W; ++e) offer(elem(sv[u], e), [&]() { return (bool)((s_valid >> (u * W + e)) & 1u); }, max(s_row[u], 0), s_c0[u] + W * lane + e);
+    constexpr int G = VEC4 ? 8 : 12;
     if (!whole) {
-        constexpr int G = VEC4 ? 8 : 12;
         auto sampled = [&](const TopkSlots<VEC4, NW>& p) {
             bool hit = false;
 #pragma unroll
@@ -3413,11 +3436,8 @@ __device__ inline void topk1_run(const TopkJob& job, SelectSharedT<NW>& sh, uint
                 if (vi[u] < 0) continue;   // (wave-uniform)
 #pragma unroll
                 for (int e = 0; e < W; ++e) {
-                    const float x = elem(v[u], e);
-                    if (__builtin_amdgcn_ballot_w64(!(x < thr)) != 0) {   // (a third of a map's registers: nobody in the wave)
-                        const int j = vc[u] + W * lane + e;
-                        keep(__float_as_uint(x), !(x < thr) && j >= vi[u] + 5 && j < L, vi[u], j);   // (the value's bits: its key when it is selected from)
-                    }
+                    const int j = vc[u] + W * lane + e;
+                    offer(elem(v[u], e), [&]() { return j >= vi[u] + 5 && j < L; }, vi[u], j);
                 }
             }
         }
@@ -3434,24 +3454,23 @@ __device__ inline void topk1_run(const TopkJob& job, SelectSharedT<NW>& sh, uint
     if (tid == 0) out_n[job.orig] = (int)n_cand;
     return;
 #endif
-    if (n_cand < kk || over) {   // the samples misjudged the map, or plateaus of equal values: the two-read kernel behind this one
-        if (tid == 0) out_n[job.orig] = -1;
+    if (over || (!count_ties && n_cand < kk)) {   // more candidates than the buffer holds, or the samples misjudged a map whose
+        if (tid == 0) out_n[job.orig] = -1;         // ties were not counted: the two-read kernel behind this one
         return;
     }
-    // (n_cand counts what passed the value test; the few that fail the key test below -- NaNs -- could leave fewer than kk:
-    //  checked again after the keys are known)
-    // ---- 3. the kk smallest of the candidates, ties to the lowest (i, j)
+    // ---- 3. the candidates' keys; how many there really are (what passed the value test and is not below the bound by its KEY
+    // -- a NaN of the wrong sign -- is no candidate)
     constexpr int E = WCAP / 64;   // (NW * WCAP candidate slots over NW * 64 threads)
     uint32_t ck[E], cij[E];
     bool have[E];
     uint32_t cmin = 0xffffffffu;
+    const uint32_t key_hi = count_ties ? (bound == 0 ? 0u : bound - 1u) : bound;   // the largest key a candidate may have
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t p = (uint32_t)(e * TH + tid);
         have[e] = (p % (uint32_t)WCAP) < sh.wave_cnt[p / (uint32_t)WCAP];
-        // (what passed the stream's value test and is not up to the bound by its KEY -- a NaN of the wrong sign -- is no candidate)
         const uint32_t xk = have[e] ? ikey(__uint_as_float(s_key[p])) : 0xffffffffu;
-        have[e] = have[e] && xk <= bound;
+        have[e] = have[e] && xk <= key_hi && (!count_ties || bound != 0);
         ck[e] = have[e] ? xk : 0xffffffffu;
         cij[e] = have[e] ? s_ij[p] : 0xffffffffu;
         cmin = min(cmin, ck[e]);
@@ -3467,24 +3486,123 @@ __device__ inline void topk1_run(const TopkJob& job, SelectSharedT<NW>& sh, uint
     }
     __syncthreads();
     cmin = sh.row_min;
-    if (sh.fill < kk) {   // (wave-uniform, workgroup-uniform)
-        if (tid == 0) out_n[job.orig] = -1;
-        return;
-    }
+    const uint32_t n_less = sh.fill;   // candidates (keys below the bound when ties are counted, up to it otherwise)
     int32_t* __restrict__ oi = out_i + job.out_off;
     int32_t* __restrict__ oj = out_j + job.out_off;
     float* __restrict__ ov = out_v + job.out_off;
-    bisect_emit<E>(ck, [&](int e) { return cij[e]; }, [&](int e) { return have[e]; }, cmin, bound, 0u, 0xfffffffeu, kk, sh,
-                   step, [&](uint32_t pos, uint32_t key_e, uint32_t ij) {
-                       const int i = (int)(ij >> 16), j = (int)(ij & 0xffffu);
-                       oi[pos] = i;
-                       oj[pos] = j;
-                       // the value from its key (1 300 scattered 4-byte reads per map were a fifth of the kernel's HBM traffic);
-                       // only a zero is read back: -0.0 and +0.0 share a key and the caller gets the map's own bits
-                       const uint32_t tk = ~key_e;
-                       const float val = __uint_as_float((tk & 0x80000000u) ? (tk & 0x7fffffffu) : ~tk);
-                       ov[pos] = val == 0.0f ? job.map[(size_t)i * job.ld + j] : val;
-                   });
+    auto emit = [&](uint32_t pos, uint32_t key_e, uint32_t ij) {
+        const int i = (int)(ij >> 16), j = (int)(ij & 0xffffu);
+        oi[pos] = i;
+        oj[pos] = j;
+        // the value from its key (1 300 scattered 4-byte reads per map were a fifth of the kernel's HBM traffic);
+        // only a zero is read back: -0.0 and +0.0 share a key and the caller gets the map's own bits
+        const uint32_t tk = ~key_e;
+        const float val = __uint_as_float((tk & 0x80000000u) ? (tk & 0x7fffffffu) : ~tk);
+        ov[pos] = val == 0.0f ? job.map[(size_t)i * job.ld + j] : val;
+    };
+    if (n_less >= kk) {   // the kk smallest of the candidates, ties to the lowest (i, j)
+        bisect_emit<E>(ck, [&](int e) { return cij[e]; }, [&](int e) { return have[e]; }, cmin, key_hi, 0u, 0xfffffffeu, kk, sh, step, emit);
+        if (tid == 0) out_n[job.orig] = job.k;
+        return;
+    }
+    if (!count_ties) {
+        if (tid == 0) out_n[job.orig] = -1;
+        return;
+    }
+    // ---- 4. fewer than kk keys below the bound: the answer is all of them + the first kk - n_less entries EQUAL to the bound in
+    // (i, j) order -- a plateau.  Rows before r* give all their ties, row r* its first few: from the per-row counts; the rows
+    // up to r* are streamed once more and every tie goes straight to its place (no buffer, no selection).
+    const uint32_t need = kk - n_less;
+    if (wave == 0) {   // exclusive prefix sums of the per-row counts, in place (uint16 wraps are harmless below: compared against need)
+        uint32_t carry = 0;
+        for (int r0 = 0; r0 < L; r0 += 64) {
+            const int r = r0 + lane;
+            const uint32_t c = r < L ? s_rowt[r] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+                incl += lane >= off ? up : 0u;
+            }
+            if (r < L) s_rowp[r] = carry + incl - c;
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0) sh.bound = carry;   // all ties of the map
+    }
+    __syncthreads();
+    if (sh.bound < need) {   // (the samples misjudged the map: even with its ties there are fewer than kk entries up to the bound)
+        if (tid == 0) out_n[job.orig] = -1;
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {   // the candidates, wherever there is room among the first n_less places
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(have[e]);
+        if (mask != 0) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&sh.pos, (uint32_t)__builtin_popcountll(mask));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (have[e]) emit(base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)), ck[e], cij[e]);
+        }
+    }
+    {
+        TopkSlots<VEC4, NW> it2;
+        it2.init(L, wave);
+        int cur_row = -1;
+        uint32_t row_run = 0;   // ties of the current row seen in its earlier chunks
+        while (!it2.done()) {
+            LV v[G];
+            int vi[G], vc[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                while (!it2.done() && s_rowp[it2.row()] >= need) it2.next();   // (rows past r*: none of their ties belongs to the answer)
+                vi[u] = -1;
+                vc[u] = 0;
+                if (!it2.done()) {
+                    vi[u] = it2.row();
+                    vc[u] = it2.col0();
+                    it2.next();
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u) v[u] = load(vi[u], vc[u]);
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                if (vi[u] < 0) continue;
+                if (vi[u] != cur_row) {
+                    cur_row = vi[u];
+                    row_run = 0;
+                }
+                unsigned long long m[W];
+                uint32_t total = 0;
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    const int j = vc[u] + W * lane + e;
+                    m[e] = __builtin_amdgcn_ballot_w64(j >= vi[u] + 5 && j < L && elem(v[u], e) == thr);
+                    total += (uint32_t)__builtin_popcountll(m[e]);
+                }
+                if (total == 0) continue;
+                const unsigned long long lower = (1ull << lane) - 1ull;
+                uint32_t before_lane = 0;   // ties of this chunk in the lanes before mine (all their columns are smaller)
+#pragma unroll
+                for (int e = 0; e < W; ++e) before_lane += (uint32_t)__builtin_popcountll(m[e] & lower);
+                uint32_t mine = 0;
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    if ((m[e] >> lane) & 1ull) {
+                        const uint32_t at = s_rowp[vi[u]] + row_run + before_lane + mine;   // place among the map's ties in (i, j) order
+                        if (at < need) {
+                            const int j = vc[u] + W * lane + e;
+                            oi[n_less + at] = vi[u];
+                            oj[n_less + at] = j;
+                            ov[n_less + at] = elem(v[u], e);
+                        }
+                        ++mine;
+                    }
+                }
+                row_run += total;
+            }
+        }
+    }
     if (tid == 0) out_n[job.orig] = job.k;
 }
 
@@ -3497,6 +3615,7 @@ __global__ __launch_bounds__(NW * 64, DCTFP_TOPK_WAVES) void contact_topk1_kerne
                                                               int32_t* __restrict__ out_n, int k_from, int k_to) {
     __shared__ SelectSharedT<NW> sh;
     __shared__ uint32_t s_key[NW * 512], s_ij[NW * 512];
+    __shared__ uint16_t s_rowt[NW == 8 ? 576 : 1216];
     const TopkJob job = jobs[blockIdx.x];
     if (job.k > 0 && job.n_res >= 6 && (job.k < k_from || job.k > k_to)) return;
     for (int q = threadIdx.x; q < kSelectCounters; q += NW * 64) sh.cnt[q] = 0;
@@ -3515,8 +3634,8 @@ __global__ __launch_bounds__(NW * 64, DCTFP_TOPK_WAVES) void contact_topk1_kerne
         if (threadIdx.x == 0) out_n[job.orig] = -1;
         return;
     }
-    if ((reinterpret_cast<uintptr_t>(job.map) & 15u) == 0 && (job.ld & 3) == 0) topk1_run<true, NW>(job, sh, s_key, s_ij, out_i, out_j, out_v, out_n);
-    else topk1_run<false, NW>(job, sh, s_key, s_ij, out_i, out_j, out_v, out_n);
+    if ((reinterpret_cast<uintptr_t>(job.map) & 15u) == 0 && (job.ld & 3) == 0) topk1_run<true, NW>(job, sh, s_key, s_ij, s_rowt, s_ij, out_i, out_j, out_v, out_n);
+    else topk1_run<false, NW>(job, sh, s_key, s_ij, s_rowt, s_ij, out_i, out_j, out_v, out_n);
 }
 
 }  // namespace dctfp
