@@ -53,6 +53,15 @@ from operator import attrgetter as _attrgetter
 _IS_CUDA, _DTYPE = _attrgetter('is_cuda'), _attrgetter('dtype')
 _KEPT_DTYPES = {torch.float32, torch.float64, torch.float16, torch.bfloat16}
 
+#: set to a list and ``fingerprint_batch`` appends (name, perf_counter()) at its stage boundaries (tools/flush_timeline.py)
+MARKS = None
+
+
+def _mark(name: str):
+    if MARKS is not None:
+        MARKS.append((name, time.perf_counter()))
+
+
 LAYERS = [15, 21]                 # src/make_db.py:78, :138
 QDIM = [3, 80, 3, 80]             # src/make_db.py:30
 THRESHOLD = 2.6                   # src/make_db.py:29
@@ -80,6 +89,7 @@ def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, thres
     from .fingerprint import _to_device_matrix, warn_constant_channel
     if not fps:
         return fps
+    _mark('start')
     lens = [len(fp.seq) for fp in fps]
     maps = [reccut._contact_tensor(fp.contacts, n) for fp, n in zip(fps, lens)]
     ctx = _lib.get_context(maps[0].device.index)
@@ -88,8 +98,10 @@ def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, thres
     # host library cost 9 us per protein on 16 threads, and the selected contacts had to come over for it); while the kernels
     # run, this thread builds the embedding tables.  What comes back is a few ints per domain.
     built = {}
+    _mark('maps')
 
     def build_tables():
+        _mark('enqueued top-k + cutter')
         keys0 = list(fps[0].embed.keys())
         mats = []
         for k in keys0:
@@ -107,8 +119,10 @@ def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, thres
                 mats[i] = [_to_device_matrix(v, keep_half=True).contiguous() for v in mats[i]]
                 layers.append(LayerBatch(mats[i], qdim[2 * i], qdim[2 * i + 1]))
         built['keys0'], built['mats'], built['layers'] = keys0, mats, layers
+        _mark('embedding tables')
 
     cut = {'doms': reccut.domains_from_maps(maps, threshold, threads=max(1, threads), before_wait=build_tables)}
+    _mark('cutter waited for + strings')
     if 'layers' not in built:
         build_tables()
     keys0, mats, layers = built['keys0'], built['mats'], built['layers']
@@ -117,9 +131,13 @@ def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, thres
             d.append(f'1-{n}')                                 # src/fingerprint.py:106-107
         fp.domains.extend(d)
     rows = [m.shape[0] for m in mats[0]]
+    _mark('domains extended')
     table = PieceTable(rows, [fp.domains for fp in fps])
+    _mark('piece table')
     out = quantize_batch(layers, table)
+    _mark('quantize enqueued')
     host8 = _to_host(out) if table.n_domains else np.zeros((0, 0), np.int8)
+    _mark('results on the host')
     if table.n_domains and ctx.get_option('degenerate_seen'):
         # rare: the flush saw an exactly constant channel (0/0 -> all-zero block, the documented deviation).  Name the proteins.
         warn_constant_channel(_constant_channel_pids(fps, mats, table) or [fp.pid for fp in fps])
@@ -137,6 +155,7 @@ def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, thres
                 fp._rows8 = host8[a:b]                         # what the writer stores (see _records)
                 continue
         _extend_quants(fp, ks, host64[a:b], qdim, len(keys0))
+    _mark('unpacked into the objects')
     if logging.getLogger().isEnabledFor(logging.INFO):         # one line per protein, as the reference writes them
         now = datetime.datetime.now()
         logging.info('\n'.join(f'{now} Fingerprinted {fp.pid}' for fp in fps))
