@@ -16,6 +16,7 @@ PKG_DIR = os.path.join(ROOT, 'dctdomain_amd')
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libdctfp.so')
 RECCUT_LIB_PATH = os.path.join(PKG_DIR, 'libreccut.so')
+TENSOR_TABLE_PATH = os.path.join(PKG_DIR, '_tensor_table.so')
 
 
 def _hipcc() -> str:
@@ -141,7 +142,42 @@ def build_all(force: bool = False, verbose: bool = False):
                 print(' '.join(cmd))
             subprocess.run(cmd, check=True)
         paths.append(RECCUT_LIB_PATH)
+    tt = build_tensor_table(force=force, verbose=verbose)
+    if tt:
+        paths.append(tt)
     return paths
+
+
+def build_tensor_table(force: bool = False, verbose: bool = False):
+    """dctdomain_amd/_tensor_table.so: the geometry of a list of torch tensors in one C++ pass (host plumbing of the Python
+    layer -- the C ABI takes plain pointers; see csrc/tensor_table.cpp).  Needs torch's headers; returns None (and the
+    Python layer reads the tensors one attribute at a time) where they are missing."""
+    src = os.path.join(CSRC, 'tensor_table.cpp')
+    if not os.path.exists(src):
+        return None
+    if not force and not _stale(TENSOR_TABLE_PATH, [src]):
+        return TENSOR_TABLE_PATH
+    try:
+        import sysconfig
+        import torch
+        from torch.utils import cpp_extension
+        incs = cpp_extension.include_paths()
+    except Exception as exc:      # noqa: BLE001  (no torch headers: the helper is optional)
+        print(f'build_ext: _tensor_table not built ({exc})')
+        return None
+    libdir = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-fPIC', '-shared',
+           f'-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}', '-I', sysconfig.get_paths()['include']]
+    for inc in incs:
+        cmd += ['-isystem', inc]
+    cmd += [src, '-o', TENSOR_TABLE_PATH, '-L', libdir, '-ltorch_python', '-lc10', '-ltorch_cpu', '-ltorch', f'-Wl,-rpath,{libdir}']
+    if verbose:
+        print(' '.join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        print('build_ext: _tensor_table failed to build (the Python layer falls back to per-tensor reads):\n' + r.stderr[-2000:])
+        return None
+    return TENSOR_TABLE_PATH
 
 
 if __name__ == '__main__':

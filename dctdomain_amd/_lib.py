@@ -56,7 +56,7 @@ EXPORTS = ('dctfp_version', 'dctfp_last_error', 'dctfp_create', 'dctfp_destroy',
            'dctfp_idct_quant', 'dctfp_scale', 'dctfp_gather_rows', 'dctfp_contact_topk',
            'dctfp_contact_count', 'dctfp_stitch', 'dctfp_l1_matrix', 'dctfp_block_min', 'dctfp_row_select', 'dctfp_row_order', 'dctfp_set_option', 'dctfp_get_option', 'dctfp_profile', 'dctfp_host_device_pointer',
            'dctfp_stream_synchronize', 'dctfp_runtime_info', 'dctfp_crash_handler', 'dctfp_build_pieces', 'dctfp_contact_sort', 'dctfp_stitch_sizes',
-           'dctfp_stitch_sequences', 'dctfp_quantize_windows', 'dctfp_reccut', 'dctfp_reccut_room', 'dctfp_quantize_one')
+           'dctfp_stitch_sequences', 'dctfp_quantize_windows', 'dctfp_reccut', 'dctfp_reccut_room', 'dctfp_quantize_one', 'dctfp_reccut_pieces')
 
 
 def load(path: str = None):
@@ -146,6 +146,8 @@ def _configure(lib):
         lib.dctfp_reccut.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
         lib.dctfp_reccut_room.argtypes = [C.c_int32]
+        lib.dctfp_reccut_pieces.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p,
+                                            C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.dctfp_idct_quant.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.dctfp_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]

@@ -115,6 +115,8 @@ class PieceTable:
         """Sequence index per output row (numpy int64)."""
         if self._lazy is not None:
             self._resolve()
+        if '_counts' in self.__dict__:
+            self._from_counts()
         return self._owner
 
     @property
@@ -122,6 +124,8 @@ class PieceTable:
         """Index of the domain string inside ``domains[s]`` per output row (numpy int64)."""
         if self._lazy is not None:
             self._resolve()
+        if '_counts' in self.__dict__:
+            self._from_counts()
         return self._source
 
     def _init_python(self, flat, counts):
@@ -149,6 +153,42 @@ class PieceTable:
         self._owner = np.asarray(owner, dtype=np.int64)
         self._source = np.asarray(source, dtype=np.int64)
         self.lengths = np.asarray(lengths, dtype=np.int64)
+
+    @classmethod
+    def from_pieces(cls, seq_rows, pieces, n_domains: int, keys: List[str], str_count):
+        """A table whose pieces were built elsewhere (``dctfp_reccut_pieces``: the domain cutter's results of a flush, strings
+        and pieces in one pass): ``keys[d]`` names output row d, ``str_count[s]`` rows belong to sequence s, in order."""
+        self = cls.__new__(cls)
+        self.seq_rows = np.ascontiguousarray(np.asarray(seq_rows, dtype=np.int64))
+        self.pieces = pieces
+        self.n_domains = int(n_domains)
+        if len(keys) != self.n_domains:
+            raise ValueError(f'{len(keys)} keys for {self.n_domains} domains')
+        self._lazy = None
+        self._keys = keys
+        self._counts = np.asarray(str_count, dtype=np.int64)
+        return self
+
+    def _from_counts(self):
+        counts = self.__dict__.pop('_counts')
+        n_seq = len(counts)
+        first = np.zeros(n_seq + 1, dtype=np.int64)
+        np.cumsum(counts, out=first[1:])
+        self._owner = np.repeat(np.arange(n_seq, dtype=np.int64), counts)
+        self._source = np.arange(self.n_domains, dtype=np.int64) - np.repeat(first[:-1], counts)
+
+    @property
+    def lengths(self):
+        """Rows of every domain (numpy int64)."""
+        v = self.__dict__.get('_lengths')
+        if v is None:
+            v = np.bincount(self.pieces['domain'], weights=self.pieces['n_rows'], minlength=self.n_domains).astype(np.int64)
+            self._lengths = v
+        return v
+
+    @lengths.setter
+    def lengths(self, v):
+        self._lengths = v
 
     @classmethod
     def whole_sequences(cls, seq_rows: Sequence[int]):
@@ -227,6 +267,37 @@ class LayerBatch:
         self.ptrs = np.ascontiguousarray(self.ptrs, dtype=np.uint64)   # host array of device pointers
         self.n_keep = int(n_keep)
         self.m_keep = int(m_keep)
+
+    @classmethod
+    def from_table(cls, tensors, ptrs, meta, n_keep: int, m_keep: int):
+        """The list constructor's checks on a geometry table of the same tensors (``_geom.tensor_table``: one C++ pass over the
+        list instead of nine Python passes -- 2 of the 6 ms a flush of 2 048 proteins spent on its embedding tables)."""
+        from . import _geom
+        n = len(tensors)
+        if n == 0:
+            raise ValueError('empty layer')
+        if not (meta[:, _geom.DIM] == 2).all():
+            raise ValueError('all sequences of a layer must be 2-D matrices')
+        t0 = tensors[0]
+        width = int(meta[0, _geom.SIZE1])
+        rows, st0 = meta[:, _geom.SIZE0], meta[:, _geom.STRIDE0]
+        longer = rows > 1               # (a matrix of one row says nothing about the row stride)
+        ld = int(st0[longer][0]) if longer.any() else width
+        if not ((meta[:, _geom.CODE] == meta[0, _geom.CODE]).all() and (meta[:, _geom.SIZE1] == width).all()
+                and (meta[:, _geom.STRIDE1] == 1).all() and (st0[longer] == ld).all()):
+            raise ValueError('all sequences of a layer must share D, dtype, device and row stride')
+        self = cls.__new__(cls)
+        self.ptrs = np.ascontiguousarray(ptrs, dtype=np.uint64)
+        self.ld = ld
+        self.n_cols = width
+        self.dtype = _dtype_code(t0)
+        self.device = t0.device
+        self._keep = tensors
+        if self.device.type != 'cuda':
+            raise ValueError('embeddings must live on the GPU (torch device "cuda")')
+        self.n_keep = int(n_keep)
+        self.m_keep = int(m_keep)
+        return self
 
 
 def host_pointer(t: torch.Tensor) -> int:

@@ -221,6 +221,8 @@ struct dctfp_ctx {
     }
     int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0, opt_ab_taper = 4, opt_ab_align = 2, opt_l1_kernel = 0, opt_row_select = 0, opt_stitch_once = 0, opt_topk_kernel = 0;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
+    int64_t last_gen_fused = 0;  // ... and whether that was the general walk kernel streaming fused walks (parts + whole protein)
+    int64_t opt_gen_fuse = 1;    // "gen_fuse": fused walks through the general walk kernel (n <= 5); 0 = the two kernels, as through round 4
     int64_t walk_launches = 0;  // walk-kernel launches so far (a call split at a giant domain ends on the two-kernel path)
     int64_t test_fail_once = 0;                    // test hook: the next dctfp_quantize fails after its table lookups
     int64_t basis_cap_doubles = (int64_t)1 << 27;  // 1 GiB of cosine tables, then the arena starts over (test hook: basis_cap_kb)
@@ -642,6 +644,8 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) try {
         ctx->opt_path = value;
     } else if (n == "fuse") {
         ctx->opt_fuse = value ? 1 : 0;
+    } else if (n == "gen_fuse") {
+        ctx->opt_gen_fuse = value ? 1 : 0;
     } else if (n == "workspace_mb") {
         if (value < 16) return fail(DCTFP_ERR_INVALID, "workspace_mb must be >= 16");
         ctx->opt_ws_mb = value;
@@ -746,6 +750,8 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) try {
     std::string n(name);
     if (n == "path") *value = ctx->opt_path;
     else if (n == "last_path") *value = ctx->last_path;
+    else if (n == "last_gen_fused") *value = ctx->last_gen_fused;
+    else if (n == "gen_fuse") *value = ctx->opt_gen_fuse;
     else if (n == "walk_launches") *value = ctx->walk_launches;
     else if (n == "fuse") *value = ctx->opt_fuse;
     else if (n == "workspace_mb") *value = ctx->opt_ws_mb;
@@ -1119,11 +1125,13 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
         // (... and it streams every job on its own: where proteins come as parts + whole protein, the fused stage A of the two
         //  kernels reads the rows once -- 3.6-4.7 against 2.1-2.3 TB/s on the c4 / c5 mixes at [5, 44] / [3, 85] / [4, 80],
         //  tools/gen_probe.py; on whole-protein batches the general kernel is 2-6 % ahead)
+        // (round 5: the general kernel has fused builds for n <= 5 -- PROST's [5, 44] / [3, 85] / [4, 80] on RecCut-shaped lists)
         const bool would_fuse = ctx->opt_fuse && n_groups > 0;
-        const bool use_gen = gen_slots > 0 && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 256 && gen_resident >= 8 && !would_fuse));
-        // (a small call wants parallelism, not fewer bytes: every job on its own workgroups; the general walk kernel streams
-        //  every job on its own)
-        const bool fuse = !trivial && n_groups > 0 && n_jobs >= 64 && !use_gen;
+        const bool gen_can_fuse = n <= kGenFusedMaxN && ctx->opt_gen_fuse;
+        const bool use_gen = gen_slots > 0 && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 256 && gen_resident >= 8 && (!would_fuse || gen_can_fuse)));
+        const bool gen_fuse = use_gen && would_fuse && gen_can_fuse && n_jobs >= 64;
+        // (a small call wants parallelism, not fewer bytes: every job on its own workgroups)
+        const bool fuse = !trivial && n_groups > 0 && n_jobs >= 64 && (!use_gen || gen_fuse);
         for (int li = 0; li < ng; ++li) {
             const dctfp_layer& ly = layers[l0 + li];
             for (int64_t d = 0; d < n_domains; ++d) {
@@ -1457,6 +1465,7 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
         if (ctx->basis_valid && ctx->basis_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_basis, 0));
 
         ctx->last_path = (use_walk || use_gen) ? 2 : 1;
+        ctx->last_gen_fused = gen_fuse ? 1 : 0;
         ctx->walk_launches += (use_walk || use_gen) ? 1 : 0;
         if (use_gen) {
             // one launch of the general walk kernel: stage A + stage B per workgroup, int8 out
@@ -1468,6 +1477,8 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             GParams gp;
             gp.jobs = dja;
             gp.jobb = djb;
+            gp.walks = dwalk;
+            gp.fused = gen_fuse;
             gp.runs = drun;
             gp.pieces = dpc;
             gp.stp = st->fragp;
@@ -2654,6 +2665,89 @@ int dctfp_build_pieces(const char* text, int64_t text_len, const int32_t* str_co
     *n_other = other;
     return DCTFP_OK;
 } DCTFP_GUARD("dctfp_build_pieces")
+
+/* The domain lists of a flush straight from dctfp_reccut's encoded results: the strings + the piece table in one pass, no text
+ * round trip (format -> split -> join -> parse).  See include/dctfp.h. */
+int dctfp_reccut_pieces(int32_t n_prot, const int32_t* enc, const int64_t* enc_off, const int64_t* seq_rows, char* text,
+                        int64_t text_cap, int64_t* text_len, int32_t* str_count, dctfp_piece* pieces, int64_t piece_cap,
+                        int64_t* n_pieces, int64_t* n_domains, int64_t* n_undone) try {
+    if (!enc || !enc_off || !seq_rows || !text || !text_len || !str_count || !pieces || !n_pieces || !n_domains || !n_undone)
+        return fail(DCTFP_ERR_INVALID, "dctfp_reccut_pieces: NULL argument");
+    if (n_prot < 0 || text_cap < 0 || piece_cap < 0) return fail(DCTFP_ERR_INVALID, "dctfp_reccut_pieces: negative size");
+    int64_t at = 0, np = 0, nd = 0, undone = 0;
+    auto put_int = [&](int64_t v) {   // decimal digits of v >= 0 (room checked by the caller: 20 bytes)
+        char tmp[24];
+        int k = 0;
+        do {
+            tmp[k++] = (char)('0' + v % 10);
+            v /= 10;
+        } while (v);
+        while (k) text[at++] = tmp[--k];
+    };
+    for (int32_t p = 0; p < n_prot; ++p) {
+        const int32_t* e = enc + enc_off[p];
+        const int64_t room = enc_off[p + 1] - enc_off[p];
+        const int64_t L = seq_rows[p];
+        str_count[p] = 0;
+        // ---- first pass: is the record whole, every segment inside the protein?  (status -1, or anything get_doms' clean-up
+        // rules would have to judge, is left to the caller: it has the host library and the string parser for those)
+        bool ok = room >= 1 && e[0] >= 1 && L >= 1;
+        int64_t q = 1, n_seg_all = 0;
+        for (int32_t d = 0; ok && d < e[0]; ++d) {
+            if (q >= room) { ok = false; break; }
+            const int32_t ns = e[q++];
+            if (ns < 1 || q + 2 * (int64_t)ns > room) { ok = false; break; }
+            for (int32_t sg = 0; sg < ns; ++sg, q += 2)
+                if (e[q] < 0 || e[q + 1] < e[q] || e[q + 1] >= L) ok = false;
+            n_seg_all += ns;
+        }
+        if (!ok) {
+            ++undone;
+            continue;
+        }
+        const bool several = e[0] > 1;
+        if (np + n_seg_all + (several ? 1 : 0) > piece_cap) return fail(DCTFP_ERR_INVALID, "dctfp_reccut_pieces: piece_cap %lld too small", (long long)piece_cap);
+        if (at + 24 * n_seg_all + 32 > text_cap) return fail(DCTFP_ERR_INVALID, "dctfp_reccut_pieces: text_cap %lld too small", (long long)text_cap);
+        if (nd + e[0] + 1 > 0x7fffffff) return fail(DCTFP_ERR_LIMIT, "dctfp_reccut_pieces: more than 2^31 domains");
+        q = 1;
+        for (int32_t d = 0; d < e[0]; ++d) {
+            const int32_t ns = e[q++];
+            for (int32_t sg = 0; sg < ns; ++sg, q += 2) {
+                if (sg) text[at++] = ',';
+                put_int((int64_t)e[q] + 1);      // 1-based, inclusive: what the binary prints (src/RecCut.cpp:440-444)
+                text[at++] = '-';
+                put_int((int64_t)e[q + 1] + 1);
+                pieces[np].row_start = e[q];     // embed[beg - 1 : end] (src/fingerprint.py:168)
+                pieces[np].n_rows = e[q + 1] - e[q] + 1;
+                pieces[np].domain = (int32_t)nd;
+                pieces[np].seq = p;
+                pieces[np].reserved = 0;
+                ++np;
+            }
+            text[at++] = ';';
+            ++nd;
+        }
+        if (several) {                           // `if len(domains) > 1: self.domains.append(f'1-{len(self.seq)}')` (src/fingerprint.py:106-107)
+            text[at++] = '1';
+            text[at++] = '-';
+            put_int(L);
+            text[at++] = ';';
+            pieces[np].row_start = 0;
+            pieces[np].n_rows = (int32_t)std::min<int64_t>(L, 0x7fffffff);
+            pieces[np].domain = (int32_t)nd;
+            pieces[np].seq = p;
+            pieces[np].reserved = 0;
+            ++np;
+            ++nd;
+        }
+        str_count[p] = e[0] + (several ? 1 : 0);
+    }
+    *text_len = at;
+    *n_pieces = np;
+    *n_domains = nd;
+    *n_undone = undone;
+    return DCTFP_OK;
+} DCTFP_GUARD("dctfp_reccut_pieces")
 
 // ---- diagnostics: which HIP / HSA runtime this library is bound to, and a crash handler that names the failing frame ----
 

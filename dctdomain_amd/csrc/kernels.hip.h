@@ -1723,13 +1723,19 @@ __device__ inline void wave_min_max64(double& mn, double& mx) {  // over all 64 
     mx = fmax(fmax(lane_value(mx, 0), lane_value(mx, 16)), fmax(lane_value(mx, 32), lane_value(mx, 48)));
 }
 
-template <typename T, int N, int VEC>
+// FUSED (round 5): the walks of walk_ab_kernel -- the parts of a protein whose last domain is the whole protein (what RecCut emits,
+// src/fingerprint.py:103-107) stream their rows ONCE: a second accumulator set collects the whole protein's coefficients against the
+// part's first row (one subtraction per element feeds both sets), its own shift restored once per part from the prefix sums
+// behind the whole protein's cosine table (see walk_ab_kernel); the whole protein is then a job that streams nothing.  Builds for
+// n <= 5 (two sets of n - 1 accumulators per channel); UNROLL 4 rows in flight there, as the fused variants of the tuned kernel.
+template <typename T, int N, int VEC, bool FUSED = false>
 __global__ __launch_bounds__(1024) void walk_gen_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
-                                                         const Run* __restrict__ runs, const PieceA* __restrict__ pieces,
+                                                         const Walk* __restrict__ walks, const Run* __restrict__ runs,
+                                                         const PieceA* __restrict__ pieces,
                                                          const double* __restrict__ stp, int8_t* __restrict__ out, int n_cols,
                                                          int64_t ld, int m, int n_slots, InvTab<N> inv,
                                                          unsigned long long* __restrict__ degenerate) {
-    constexpr int NK = N - 1, TILES = (N + 3) / 4, UNROLL = 8;
+    constexpr int NK = N - 1, TILES = (N + 3) / 4, UNROLL = FUSED ? 4 : 8;
     extern __shared__ double lds_dyn[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1753,9 +1759,25 @@ __global__ __launch_bounds__(1024) void walk_gen_kernel(const JobA* __restrict__
     const int col_bytes = (pad ? 0 : ch0) * (int)sizeof(T);
     const int ld_bytes = (int)(ld * (int64_t)sizeof(T));
 
-    for (uint32_t jn = 0; jn < run.n_jobs; ++jn) {
-        const JobA job = jobs[run.job_begin + jn];
-        const PieceA* __restrict__ pc = pieces + job.piece_begin;
+    uint32_t jn = 0;   // jobs of this run behind us (the jobs of a run are consecutive: job = run.job_begin + jn)
+    const uint32_t n_walks = FUSED ? run.n_walks : run.n_jobs;   // (not FUSED: every job is a walk of its own, the table is not read)
+    for (uint32_t wi = 0; wi < n_walks; ++wi) {
+        uint32_t n_parts = 1;
+        int32_t whole_job = -1;
+        if constexpr (FUSED) {
+            const Walk wk = walks[run.walk_begin + wi];
+            n_parts = wk.n_parts;
+            whole_job = wk.whole_job;
+        }
+        const bool has_w = FUSED && whole_job >= 0;
+        const uint32_t n_walk_jobs = n_parts + (has_w ? 1u : 0u);
+        double wacc[FUSED ? (NK > 0 ? NK : 1) : 1][VEC];
+#pragma unroll
+        for (int k = 0; k < (FUSED ? NK : 1); ++k)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) wacc[k][v] = 0.0;
+        const uint32_t w_rows = has_w ? jobs[whole_job].n_rows : 0u;   // rows of the whole protein = offset of the prefix sums behind its cosine table
+    for (uint32_t part = 0; part < n_walk_jobs; ++part, ++jn) {
         const uint32_t slot = jn % (uint32_t)n_slots, before = jn / (uint32_t)n_slots;   // jobs that used this slot before
         double* const ys = lds_dyn + (size_t)slot * slot_doubles;                         // Y'[N][CH]
         // partial Z of wave w, row j: pz(w, j)[0 .. cp)
@@ -1765,26 +1787,43 @@ __global__ __launch_bounds__(1024) void walk_gen_kernel(const JobA* __restrict__
         for (int k = 0; k < NK; ++k)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) f[k][v] = 0.0;
-        // ---- stage A: every row of my channels
-        if (!pad) {
+        if (part >= n_parts) {   // the whole protein of a fused walk: its coefficients have been collected while the parts streamed by
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) f[k][v] = wacc[FUSED ? k : 0][v];
+        } else if (!pad) {
+            // ---- stage A: every row of my channels
+            const JobA job = jobs[run.job_begin + jn];
+            const PieceA* __restrict__ pc = pieces + job.piece_begin;
             double ref[VEC];
             {
                 const Rw r0 = load_raw<T, VEC>(reinterpret_cast<const T*>(pc[0].ptr) + ch0);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) ref[v] = raw_elem<T, VEC>(r0, v);
             }
-            for (uint32_t p = 0; p < job.n_pieces; ++p) {
-                const PieceA piece = pc[p];
+            double cwsum[NK > 0 ? NK : 1];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) cwsum[k] = 0.0;
+            // (the test of `has_w` must not sit inside the row loop: see walk_ab_kernel)
+            auto stream_piece = [&](auto hw_tag, const PieceA& piece) {
+                constexpr bool HW = decltype(hw_tag)::value;
                 const __amdgpu_buffer_rsrc_t rows = wave_buffer(piece.ptr);
                 const CosTab btp = cos_tab(job.basis) + (size_t)piece.t0 * NK;
+                const CosTab wtp = cos_tab(job.w_basis) + (size_t)piece.w0 * NK;
                 auto load_row = [&](uint32_t r) { return buffer_load_any<Rw>(rows, col_bytes, (int)r * ld_bytes); };
                 auto row_update = [&](const Rw& x, uint32_t r) {
                     const CosTab c = btp + (size_t)r * NK;
+                    const CosTab cw = wtp + (size_t)r * NK;
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         const double d = raw_elem<T, VEC>(x, v) - ref[v];
 #pragma unroll
                         for (int k = 0; k < NK; ++k) f[k][v] = fma(c[k], d, f[k][v]);
+                        if constexpr (HW) {
+#pragma unroll
+                            for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(cw[k], d, wacc[FUSED ? k : 0][v]);
+                        }
                     }
                 };
                 uint32_t r = 0;
@@ -1795,13 +1834,15 @@ __global__ __launch_bounds__(1024) void walk_gen_kernel(const JobA* __restrict__
 #pragma unroll
                     for (int u = 0; u < UNROLL; ++u) row_update(xv[u], r + u);
                 }
-                if (r + 4 <= piece.n_rows) {
-                    Rw xv[4];
+                if constexpr (UNROLL > 4) {
+                    if (r + 4 <= piece.n_rows) {
+                        Rw xv[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) xv[u] = load_row(r + u);
+                        for (int u = 0; u < 4; ++u) xv[u] = load_row(r + u);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) row_update(xv[u], r + u);
-                    r += 4;
+                        for (int u = 0; u < 4; ++u) row_update(xv[u], r + u);
+                        r += 4;
+                    }
                 }
                 if (r < piece.n_rows) {
                     Rw xv[3];
@@ -1811,6 +1852,25 @@ __global__ __launch_bounds__(1024) void walk_gen_kernel(const JobA* __restrict__
 #pragma unroll
                     for (int u = 0; u < 3; ++u)
                         if (r + u < piece.n_rows) row_update(xv[u], r + u);
+                }
+                if constexpr (HW) {  // prefix sums past this piece's last and at its first row
+                    const CosTab wpre = wtp + (size_t)w_rows * NK;
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) cwsum[k] += wpre[(size_t)piece.n_rows * NK + k] - wpre[k];
+                }
+            };
+            for (uint32_t p = 0; p < job.n_pieces; ++p) {
+                const PieceA piece = pc[p];
+                if (FUSED && has_w) stream_piece(std::integral_constant<bool, FUSED>{}, piece);
+                else stream_piece(std::false_type{}, piece);
+            }
+            if (FUSED && has_w) {   // the whole protein's own shift:  sum_t cw(t) (x_t - r_w) = sum_t cw(t) (x_t - r_p) + (r_p - r_w) sum_t cw(t)
+                const Rw w0 = load_raw<T, VEC>(reinterpret_cast<const T*>(job.w_ref) + ch0);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const double dr = ref[v] - raw_elem<T, VEC>(w0, v);
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) wacc[FUSED ? k : 0][v] = fma(dr, cwsum[k], wacc[FUSED ? k : 0][v]);
                 }
             }
         }
@@ -1894,6 +1954,7 @@ __global__ __launch_bounds__(1024) void walk_gen_kernel(const JobA* __restrict__
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_fetch_add(&counters[2 + slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+    }
     }
 }
 

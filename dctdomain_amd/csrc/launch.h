@@ -98,6 +98,8 @@ struct WParams {
 struct GParams {
     const JobA* jobs;
     const JobB* jobb;
+    const Walk* walks;   // fused: the walks of the runs (parts + whole protein); else unused
+    bool fused;
     const Run* runs;
     const PieceA* pieces;
     const double* stp;
@@ -114,6 +116,7 @@ struct GParams {
 };
 
 constexpr size_t kGenLdsBudget = 150 * 1024;  // of the 160 KB of a CU
+constexpr int kGenFusedMaxN = 5;              // fused walks of the general kernel: two sets of n - 1 accumulators per channel
 
 // LDS of one slot: Y'[N][CH] float64; the partial Z blocks [S][N][cp] reuse it unless a wave's columns are too few
 inline size_t gen_slot_bytes(int n, int m, int waves, int vec) {

@@ -44,7 +44,7 @@ struct CutJob {
     uint32_t* adj;       // scratch: 2 * n_contacts + 6 * n_res entries (neighbour | weight << 16)
     int32_t* stack;      // scratch: kCutStack * kCutNodeInts
     int32_t* out;        // {n_domains or -1, then per domain: n_segs, (first, last) ...}, 0-based residues
-    unsigned long long* timing;   // instrumented build (-DDCTFP_CUT_TIMING): 8 phase totals of the whole launch (100 MHz ticks), else unused
+    unsigned long long* timing;   // instrumented build (-DDCTFP_CUT_TIMING): 11 phase totals of the whole launch (100 MHz ticks), else unused
     int32_t n_contacts;
     int32_t n_res;
     int32_t out_cap;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kCutThreads) void reccut_kernel(const CutJob* __res
     const int L = job.n_res;
     int32_t* __restrict__ out = job.out;
 #ifdef DCTFP_CUT_TIMING
-    unsigned long long tl_prev = __builtin_amdgcn_s_memrealtime(), tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tl_prev = __builtin_amdgcn_s_memrealtime(), tl_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define CUT_T(k)                                                          \
     do {                                                                  \
         const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kCutThreads) void reccut_kernel(const CutJob* __res
 #define CUT_T_OUT()                                                                     \
     do {                                                                                \
         if (tid == 0 && job.timing)                                                     \
-            for (int q_ = 0; q_ < 8; ++q_) atomicAdd(job.timing + q_, tl_acc[q_]);      \
+            for (int q_ = 0; q_ < 11; ++q_) atomicAdd(job.timing + q_, tl_acc[q_]);      \
     } while (0)
 #else
 #define CUT_T(k)
@@ -397,6 +397,7 @@ __global__ __launch_bounds__(kCutThreads) void reccut_kernel(const CutJob* __res
                 }
             }
             __syncthreads();
+            CUT_T(3);    // tile fill + its barrier
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
                 const int g = wave + sl * NWV;
@@ -465,7 +466,9 @@ __global__ __launch_bounds__(kCutThreads) void reccut_kernel(const CutJob* __res
                 }
                 below[sl] = bl;
             }
+            CUT_T(8);    // this wave's rows
             __syncthreads();   // (every wave has read the tile)
+            CUT_T(9);    // the wait for the slowest wave of the block
             if (tid < n_rows * FPR) {
                 const int t_row = tid / FPR, row = hi - t_row;
                 const int e1 = foff[row] + tmp[row];
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(kCutThreads) void reccut_kernel(const CutJob* __res
             }
             // (the next block's fill by the same threads follows without a barrier only for their own entries: a barrier for the rest)
             __syncthreads();
+            CUT_T(10);   // tile cleared
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(kCutThreads) void reccut_kernel(const CutJob* __res
             red_j[wave] = b2j;
         }
         __syncthreads();
-        CUT_T(3);   // double-cut scan (this wave's share + the wait for the others)
+        CUT_T(3);   // (instrumented build: 3 = tile fills, 8 = wave 0's rows, 9 = its wait for the block's slowest wave, 10 = tile clears)
         // ---- decision and bookkeeping: thread 0 (segments and cut sites are a handful of ints)
         if (tid == 0) {
             double best2 = 2.0;

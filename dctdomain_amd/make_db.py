@@ -19,6 +19,7 @@ interrupted build resumes where it stopped (``fpcount``, src/database.py:150, :2
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import datetime
 import logging
 import os
@@ -76,8 +77,223 @@ def queue_cpu(fp: Fingerprint) -> Fingerprint:
 
 
 def fingerprint_batch(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, threshold: float = THRESHOLD):
-    """``queue_cpu`` for many proteins at once: same ``domains`` / ``quants`` per object as calling
-    it one by one, with three batched steps instead of a process pool (src/make_db.py:36-51).
+    """``queue_cpu`` for many proteins at once: same ``domains`` / ``quants`` per object as calling it one by one
+    (src/make_db.py:19-33 inside the pool of :36-51).  The flush as ``_Flush`` runs it -- geometry of all tensors in one pass,
+    contact selection + domain cutter on the GPU, strings and piece table straight from the cutter's integers, one
+    ``dctfp_quantize``, the objects filled while the kernels run; anything out of the ordinary (domains or fingerprints already
+    in an object, embeddings that are not GPU tensors of one layout, a protein whose domain strings need Python's own parser)
+    goes through ``_fingerprint_batch_generic``, which takes every input the reference takes."""
+    if not fps:
+        return fps
+    fl = _Flush(fps, threads, qdim, threshold)
+    if fl.start():
+        if fl.finish(objects=True) is not None:
+            LAST_PATH[0] = 'flush'
+            return fps
+    LAST_PATH[0] = 'generic'
+    return _fingerprint_batch_generic(fps, threads, qdim, threshold)
+
+
+#: which way the last ``fingerprint_batch`` / ``flush_records`` of this process went ('flush' or 'generic'): tests assert it
+LAST_PATH = [None]
+
+
+_SEQ, _CONTACTS, _EMBED, _DOMAINS, _QUANTS, _PID = (_attrgetter(a) for a in ('seq', 'contacts', 'embed', 'domains', 'quants', 'pid'))
+_SIDE_STREAMS = {}
+_FLUSH_SLOT = [0]
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device)
+    if s is None:
+        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device)
+    return s
+
+
+class _Flush:
+    """One flush of a database build in two halves, so that the build can do something else in between
+    (``process_sequences`` embeds the next proteins; the domain cutter is a latency, not a load: a few long proteins, one
+    workgroup each):
+
+    ``start()``   geometry of every tensor of the flush in one pass (``_geom``), contact selection + domain cutter enqueued on a
+                  side stream, results on their way into page-locked memory; the embedding tables while the GPU works.
+    ``finish()``  the cutter's integers -> strings + piece table (``dctfp_reccut_pieces``), one ``dctfp_quantize``, the
+                  per-protein results assembled while the kernels run.  ``objects=True`` fills ``domains`` / ``quants`` of every
+                  ``Fingerprint`` as ``queue_cpu`` does (int64 rows, the reference's dtype) and returns the list;
+                  ``objects=False`` returns what the writer stores -- (pid, domains, int8 rows) -- and leaves the objects alone.
+
+    Both return None / False where the flush is not of the plain kind; the caller then runs ``_fingerprint_batch_generic``."""
+
+    def __init__(self, fps, threads=1, qdim=QDIM, threshold=THRESHOLD):
+        self.fps, self.threads, self.qdim, self.threshold = fps, max(1, threads), list(qdim), threshold
+        self.cut = None
+
+    def start(self) -> bool:
+        from . import _geom, reccut
+        from .batch import LayerBatch
+        fps = self.fps
+        n = len(fps)
+        _mark('start')
+        if any(map(_DOMAINS, fps)) or any(map(_QUANTS, fps)):
+            return False                       # (domains given by the caller, or a second quantize: the general bookkeeping)
+        seqs = list(map(_SEQ, fps))
+        lens = np.fromiter(map(len, seqs), dtype=np.int64, count=n)
+        cts = list(map(_CONTACTS, fps))
+        ptrs, meta = _geom.tensor_table(cts)
+        first = cts[0]
+        if not (torch.is_tensor(first) and first.is_cuda and first.dtype == torch.float32):
+            return False
+        side = lens > 1
+        if not ((meta[:, _geom.DIM] == 2).all() and (meta[:, _geom.CODE] == meta[0, _geom.CODE]).all()
+                and (meta[:, _geom.SIZE0] == lens).all() and (meta[:, _geom.SIZE1] == lens).all()
+                and (meta[side, _geom.STRIDE1] == 1).all() and (lens >= 1).all() and lens.max() < (1 << 31)):
+            return False                       # (maps given as numpy / flat / transposed: _contact_tensor judges them one by one)
+        device = first.device
+        lds = np.where(side, meta[:, _geom.STRIDE0], np.maximum(lens, 1))
+        self.lens = lens
+        keys0 = list(fps[0].embed.keys())
+        if not keys0:
+            return False
+        embeds = list(map(_EMBED, fps))
+        _mark('maps')
+        ctx = _lib_mod().get_context(device.index)
+        self.ctx, self.device = ctx, device
+        slot = _FLUSH_SLOT[0] = _FLUSH_SLOT[0] ^ 1
+        main = torch.cuda.current_stream(device)
+        stream = _side_stream(device)
+        stream.wait_stream(main)               # (the maps were written on the caller's stream)
+        self.cut = reccut.CutInFlight(ptrs, lds, lens.astype(np.int32), device, self.threshold, stream=stream, slot=slot)
+        self._maps = cts
+        _mark('enqueued top-k + cutter')
+        # ---- the embedding tables, while the GPU selects and cuts
+        layers, mats = [], []
+        try:
+            for i, k in enumerate(keys0):
+                vals = [e[k] for e in embeds]
+                p, m = _geom.tensor_table(vals)
+                if not (m[:, _geom.SIZE0] == lens).all():
+                    return self._abandon()     # (rows of an embedding differ from the sequence's length: the general path names it)
+                t0 = vals[0]
+                if not (t0.is_cuda and t0.dtype in _KEPT_DTYPES and t0.device == device):
+                    return self._abandon()
+                layers.append(LayerBatch.from_table(vals, p, m, self.qdim[2 * i], self.qdim[2 * i + 1]))
+                mats.append(vals)
+        except (ValueError, KeyError, AttributeError, TypeError, IndexError):
+            return self._abandon()
+        self.layers, self.mats, self.keys0 = layers, mats, keys0
+        _mark('embedding tables')
+        return True
+
+    def _abandon(self):
+        if self.cut is not None:
+            self.cut.done.synchronize()        # (its buffers are this thread's: nothing may still be writing them)
+            self.cut = None
+        return False
+
+    def finish(self, objects: bool):
+        from .batch import PieceTable, quantize_batch
+        fps, n, lens = self.fps, len(self.fps), self.lens
+        lib = _lib_mod().load()
+        enc = self.cut.wait()
+        _mark('cutter waited for')
+        enc_off = self.cut.enc_off
+        n_enc = int(enc_off[-1])
+        # (segments + proteins bound the pieces; 24 bytes per segment + 32 per protein the text: an encoded record spends two
+        #  ints per segment)
+        piece_cap = n_enc // 2 + n + 1
+        text_cap = 12 * n_enc + 32 * n + 64
+        pieces = np.empty(piece_cap, dtype=_lib_mod().PIECE_DTYPE)
+        text = np.empty(text_cap, dtype=np.uint8)
+        counts = np.empty(n, dtype=np.int32)
+        text_len, n_pieces, n_dom, n_undone = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        enc = np.ascontiguousarray(enc)
+        _lib_mod().check(lib.dctfp_reccut_pieces(n, enc.ctypes.data, enc_off.ctypes.data, lens.ctypes.data, text.ctypes.data, text_cap,
+                                                C.byref(text_len), counts.ctypes.data, pieces.ctypes.data, piece_cap, C.byref(n_pieces),
+                                                C.byref(n_dom), C.byref(n_undone)), lib)
+        if n_undone.value:
+            return None                        # (a protein whose strings Python's own parser must judge: never seen; the general path)
+        flat = text[:text_len.value].tobytes().decode('ascii').split(';')
+        flat.pop()
+        nd = n_dom.value
+        table = PieceTable.from_pieces(lens, pieces[:n_pieces.value], nd, flat, counts)
+        _mark('strings + piece table')
+        total = sum(l.n_keep * l.m_keep for l in self.layers)
+        self.ctx.get_option('degenerate_seen')  # (the flag is the context's: drop what earlier callers left unread)
+        out = quantize_batch(self.layers, table, ctx=self.ctx)
+        stream = torch.cuda.current_stream(self.device)
+        pin = getattr(_PINNED, 'buf', None)
+        if pin is None or pin.numel() < nd * total:
+            pin = _PINNED.buf = torch.empty(max(nd * total + nd * total // 4, 1 << 20), dtype=torch.int8, pin_memory=True)
+        view = pin[:nd * total].view(nd, total)
+        view.copy_(out, non_blocking=True)
+        _mark('quantize enqueued')
+        # ---- everything that needs only the SHAPE of the result, while the kernels run
+        bounds = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(counts, out=bounds[1:])
+        bl = bounds.tolist()
+        host8 = np.empty((nd, total), dtype=np.int8)
+        result = None
+        if objects:
+            host64 = np.empty((nd, total), dtype=np.int64)      # np.array(list of ints) in the reference: int64
+            rows64 = list(host64)                               # (row views, made in one C-level pass)
+            dup = []
+            for s, fp in enumerate(fps):
+                a, b = bl[s], bl[s + 1]
+                ks = flat[a:b]
+                q = dict(zip(ks, rows64[a:b]))                  # a row already is layer 0's block, layer 1's block, ... (:184-196)
+                if len(q) != b - a:                             # (a key twice: never from the cutter -- its domains are disjoint)
+                    dup.append(s)
+                    continue
+                fp.quants = q
+                fp.domains = ks
+                fp._rows8 = host8[a:b]                          # what the writer stores (see _records)
+            result = fps
+        else:
+            result = [(pid, flat[a:b], host8[a:b]) for pid, a, b in zip(map(_PID, fps), bl[:-1], bl[1:])]
+        _mark('results laid out')
+        stream.synchronize()
+        np.copyto(host8, view.numpy())
+        if objects:
+            np.copyto(host64, host8)
+            for s in dup:
+                a, b = bl[s], bl[s + 1]
+                fps[s].domains.extend(flat[a:b])
+                _extend_quants(fps[s], flat[a:b], host64[a:b], self.qdim, len(self.keys0))
+        _mark('results on the host')
+        if nd and self.ctx.get_option('degenerate_seen'):
+            # rare: the flush saw an exactly constant channel (0/0 -> all-zero block, the documented deviation).  Name the proteins.
+            from .fingerprint import warn_constant_channel
+            warn_constant_channel(_constant_channel_pids(fps, self.mats, table) or [fp.pid for fp in fps])
+        if logging.getLogger().isEnabledFor(logging.INFO):      # one line per protein, as the reference writes them
+            now = datetime.datetime.now()
+            logging.info('\n'.join(f'{now} Fingerprinted {fp.pid}' for fp in fps))
+        self.cut = None
+        return result
+
+
+def _lib_mod():
+    from . import _lib
+    return _lib
+
+
+def flush_records(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, threshold: float = THRESHOLD):
+    """What the writer stores for a flush -- (pid, domains, int8 rows) per protein, the files' content -- without filling the
+    ``Fingerprint`` objects (``make_db`` never looks at them again).  Same values as ``_records(fingerprint_batch(fps))``."""
+    if not fps:
+        return []
+    fl = _Flush(fps, threads, qdim, threshold)
+    if fl.start():
+        recs = fl.finish(objects=False)
+        if recs is not None:
+            LAST_PATH[0] = 'flush'
+            return recs
+    LAST_PATH[0] = 'generic'
+    return _records(_fingerprint_batch_generic(fps, threads, qdim, threshold))
+
+
+def _fingerprint_batch_generic(fps: List[Fingerprint], threads: int = 1, qdim=QDIM, threshold: float = THRESHOLD):
+    """The flush for every input the reference takes (numpy or CPU tensors, domains already present, a second ``quantize``
+    on the same objects, strings only Python's parser can judge): what ``fingerprint_batch`` was through round 5's first half.
 
     Nothing in here loops over domains in Python (the flush used to cost 117 us per protein against < 1 us
     of kernels): the contact selection is one GPU call, RecCut one threaded C call that runs while this thread prepares
@@ -258,12 +474,31 @@ def process_sequences(seqs, model, device, maxlen: int, cpu: int, flush: int, si
             for emb in bt.embeds:
                 queue.append(Fingerprint(pid=emb.pid, seq=emb.seq, embed=emb.embed, contacts=emb.contacts))
 
+    # A flush in two halves (``_Flush``): its contact selection and domain cutter are enqueued when the queue is full, its second
+    # half -- strings, piece table, dctfp_quantize, records -- runs when the NEXT queue is full (or the input ends): the cutter is
+    # a latency (a few long proteins, one workgroup each, 3-5 ms per 2 048 proteins), and it passes while the next proteins are
+    # embedded.  Records reach the writer in sequence order all the same.
+    pending = []
+
+    def finish_pending():
+        while pending:
+            fl, q = pending.pop(0)
+            with stage('fingerprint (contact top-k + RecCut + dctfp_quantize)'):
+                recs = fl.finish(objects=False) if fl is not None else None
+                if recs is None:
+                    recs = _records(_fingerprint_batch_generic(q, threads=cpu))
+            with stage('hand over to the writer'):
+                sink(recs)
+
     def flush_queue():
-        with stage('fingerprint (contact top-k + RecCut + dctfp_quantize)'):
-            recs = _records(fingerprint_batch(queue, threads=cpu))
-        with stage('hand over to the writer'):
-            sink(recs)
+        q = list(queue)
         queue.clear()
+        with stage('fingerprint (contact top-k + RecCut + dctfp_quantize)'):
+            fl = _Flush(q, threads=cpu)
+            if not fl.start():
+                fl = None
+        finish_pending()
+        pending.append((fl, q))
 
     for pid, seq in seqs:                          # same packing rule as Database.yield_seqs
         if batch and (cur + len(seq) > maxlen or len(batch) > cpu):
@@ -277,6 +512,7 @@ def process_sequences(seqs, model, device, maxlen: int, cpu: int, flush: int, si
         run_batch(batch)
     if queue:
         flush_queue()
+    finish_pending()
 
 
 def _gpu_worker(rank: int, n_gpu: int, shards, model_name: str, maxlen: int, cpu: int, flush: int, out_q):

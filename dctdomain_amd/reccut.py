@@ -199,6 +199,100 @@ def _cut_on_device(n_res, counts, offs, oi, oj, ov, on, cut1, cut2, threads, bef
     return doms
 
 
+def reccut_room(n_res: np.ndarray) -> np.ndarray:
+    """``dctfp_reccut_room`` for an array of lengths (the C function is the definition; tests hold this to it)."""
+    n = np.asarray(n_res, dtype=np.int64)
+    doms = np.where(n > 0, n // 22 + 1, 1)
+    return 2 + doms + 2 * (2 * doms + 1)
+
+
+class CutInFlight:
+    """Contact selection + domain cutter of a batch, enqueued on ``stream`` (``dctfp_contact_topk`` + ``dctfp_reccut``), the
+    encoded results on their way into a page-locked buffer: what a database flush starts early and picks up when it needs
+    the domains (``make_db._Flush``).  ``ptrs`` / ``lds`` / ``n_res``: the contact maps' geometry (``_geom.tensor_table``)."""
+
+    def __init__(self, ptrs, lds, n_res, device, t: float, cut1=CUT1_DEFAULT, cut2=CUT2_DEFAULT, stream=None, slot: int = 0):
+        lib = _lib.load()
+        n = len(n_res)
+        self.n = n
+        self.n_res = np.ascontiguousarray(n_res, dtype=np.int32)
+        L64 = self.n_res.astype(np.int64)
+        cand = np.where(L64 >= 6, (L64 - 5) * (L64 - 4) // 2, 0)
+        self.counts = np.minimum(np.maximum((float(t) * L64.astype(np.float64)).astype(np.int64), 0), cand)
+        self.offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(self.counts, out=self.offs[1:])
+        total = int(self.offs[-1])
+        self.cut1, self.cut2 = float(cut1), float(cut2)
+        self.stream = stream if stream is not None else torch.cuda.current_stream(device)
+        ptrs = np.ascontiguousarray(ptrs, dtype=np.uint64)
+        lds = np.ascontiguousarray(lds, dtype=np.int64)
+        with torch.cuda.stream(self.stream):
+            self.oi = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+            self.oj = torch.empty(max(total, 1), dtype=torch.int32, device=device)
+            self.ov = torch.empty(max(total, 1), dtype=torch.float32, device=device)
+            on = torch.zeros(n, dtype=torch.int32, device=device)
+            ctx = _lib.get_context(device.index)
+            sp = C.c_void_p(self.stream.cuda_stream)
+            _lib.check(lib.dctfp_contact_topk(ctx.handle, ptrs.ctypes.data, lds.ctypes.data, self.n_res.ctypes.data, n, float(t),
+                                              self.oi.data_ptr(), self.oj.data_ptr(), self.ov.data_ptr(), self.offs.ctypes.data,
+                                              on.data_ptr(), sp), lib)
+            room = reccut_room(self.n_res)
+            self.enc_off = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(room, out=self.enc_off[1:])
+            n_enc = int(self.enc_off[-1])
+            enc = torch.empty(n_enc, dtype=torch.int32, device=device)
+            _lib.check(lib.dctfp_reccut(ctx.handle, self.n_res.ctypes.data, n, self.oi.data_ptr(), self.oj.data_ptr(), self.ov.data_ptr(),
+                                        self.offs.ctypes.data, self.cut1, self.cut2, enc.data_ptr(), self.enc_off.ctypes.data, sp), lib)
+            self.penc = _pinned(f'enc{slot}', torch.int32, n_enc)
+            self.penc.copy_(enc, non_blocking=True)
+            self.pn = _pinned(f'n{slot}', torch.int32, n)
+            self.pn.copy_(on, non_blocking=True)
+            self.done = torch.cuda.Event()
+            self.done.record(self.stream)
+        self._keep = (enc, on)
+
+    def wait(self) -> np.ndarray:
+        """The encoded results (host view, valid until this thread's next batch in the same slot); proteins the GPU cutter
+        handed back (status -1) are redone by the host library here and written into the same encoding."""
+        self.done.synchronize()
+        if not (self.pn.numpy() == self.counts).all():
+            raise RuntimeError('dctfp_contact_topk wrote a different number of contacts than dctfp_contact_count says')
+        enc = self.penc.numpy()
+        redo = np.flatnonzero(enc[self.enc_off[:-1]] < 1)
+        LAST.host_redo = redo.tolist()
+        self.redo_strings = {}
+        if len(redo):
+            sel_off = np.zeros(len(redo) + 1, dtype=np.int64)
+            np.cumsum(self.counts[redo], out=sel_off[1:])
+            pick = np.concatenate([np.arange(self.offs[p], self.offs[p + 1]) for p in redo]) if sel_off[-1] else np.zeros(0, np.int64)
+            pick_t = torch.from_numpy(pick).to(self.oi.device)
+            hi, hj, hv = (x[pick_t].cpu().numpy() for x in (self.oi, self.oj, self.ov))
+            for p, d in zip(redo.tolist(), domains_from_contacts(self.n_res[redo], sel_off, hi, hj, hv, self.cut1, self.cut2)):
+                self.redo_strings[p] = d
+                rec = _encode_domains(d)
+                a, b = int(self.enc_off[p]), int(self.enc_off[p + 1])
+                if rec is not None and len(rec) <= b - a:
+                    enc[a:a + len(rec)] = rec           # (else: status stays -1 and the caller parses the strings itself)
+        return enc
+
+
+def _encode_domains(doms: List[str]):
+    """Domain strings of the binary ("b-e[,b-e]*", 1-based inclusive) in ``dctfp_reccut``'s encoding, or None for anything else."""
+    rec = [len(doms)]
+    try:
+        for d in doms:
+            segs = d.split(',')
+            rec.append(len(segs))
+            for sg in segs:
+                b, e = sg.split('-')
+                if not (b.isdigit() and e.isdigit()):
+                    return None
+                rec += [int(b) - 1, int(e) - 1]
+    except ValueError:
+        return None
+    return np.asarray(rec, dtype=np.int32) if doms else None
+
+
 def domains_from_maps(maps: Sequence[torch.Tensor], t: float, cut1=CUT1_DEFAULT, cut2=CUT2_DEFAULT, threads: int = 1,
                       before_wait=None) -> List[List[str]]:
     """``Fingerprint.reccut``'s domain lists for a batch of contact maps with NOTHING but the answer leaving the GPU: the contact

@@ -214,6 +214,22 @@ int dctfp_reccut(dctfp_ctx* ctx, const int32_t* n_res, int32_t n_prot, const int
                  const int64_t* offs, double cut1, double cut2, int32_t* out, const int64_t* out_offs, void* stream);
 int64_t dctfp_reccut_room(int32_t n_res);
 
+/* What Fingerprint.reccut appends to `domains` (src/fingerprint.py:103-107) and what Fingerprint.get_doms makes of those strings
+ * (:163-169), for a whole flush, straight from dctfp_reccut's encoded results (host copies of them): per protein the strings the
+ * binary prints -- "b-e[,b-e]*", 1-based inclusive -- followed by "1-L" where there are several, each terminated by ';' in
+ * `text`; str_count[p] = strings of protein p; and the dctfp_piece table of exactly those strings (domain = running index over
+ * all strings, seq = p), ready for dctfp_quantize.  A flush of 2 048 proteins used to format the strings in one library, split
+ * them per protein, join them again and parse them in dctfp_build_pieces.
+ *   enc, enc_off : as dctfp_reccut wrote them (enc_off[n_prot] entries; protein p at enc + enc_off[p]);  seq_rows[p] = residues
+ *   text_cap     : 24 bytes per segment + 32 per protein is always enough;  piece_cap : segments + proteins
+ *   *n_undone    : proteins left out (str_count[p] = 0, no pieces): status -1, a malformed record, or a segment outside the
+ *                  protein (which get_doms' clean-up rules would have to judge): run reccut_predict / dctfp_build_pieces on
+ *                  those -- the table then speaks of the other proteins only.
+ * Host memory only; needs no GPU and no context. */
+int dctfp_reccut_pieces(int32_t n_prot, const int32_t* enc, const int64_t* enc_off, const int64_t* seq_rows, char* text,
+                        int64_t text_cap, int64_t* text_len, int32_t* str_count, dctfp_piece* pieces, int64_t piece_cap,
+                        int64_t* n_pieces, int64_t* n_domains, int64_t* n_undone);
+
 /* The chunk stitcher of Embedding.embed_seq (src/embedding.py:153-192): a sequence longer than
  * maxlen is embedded in windows; per layer `run[-200:] = (run[-200:] + new[:200]) / 2` then
  * `cat(new[200:])` (:185-187), and for the contact maps combine_contacts (:123-150).  One job =

@@ -277,3 +277,120 @@ def test_ranked_hits_is_the_reference_list_sort():
         assert list(zip(ii, jj)) == ref
         assert [str(s) for s in scores] == [str(round(1 - (top_hits[key] / 17000), 4)) for key in ref]
 
+
+
+def _random_encoding(rng, n_prot):
+    """Records as dctfp_reccut writes them, with room to spare: {D, then per domain n_segs, (first, last) ...}."""
+    from dctdomain_amd import reccut
+    lens = rng.integers(22, 900, size=n_prot)
+    room = reccut.reccut_room(lens)
+    enc_off = np.zeros(n_prot + 1, dtype=np.int64)
+    np.cumsum(room, out=enc_off[1:])
+    enc = np.full(int(enc_off[-1]), -7, dtype=np.int32)
+    expect = []
+    for p, L in enumerate(lens.tolist()):
+        n_dom = int(rng.integers(1, max(2, min(6, L // 22 + 1))))
+        cuts = np.sort(rng.choice(np.arange(1, L), size=2 * n_dom - 1, replace=False)) if L > 2 * n_dom else np.arange(1, 2 * n_dom)
+        bounds = [0] + cuts.tolist() + [L]
+        segs = [(bounds[i], bounds[i + 1] - 1) for i in range(len(bounds) - 1)]        # 2 n_dom segments tiling the protein
+        rng.shuffle(segs)
+        rec, doms = [n_dom], []
+        for d in range(n_dom):
+            mine = segs[2 * d:2 * d + 2] if d < n_dom - 1 else segs[2 * d:]
+            rec.append(len(mine))
+            for a, b in mine:
+                rec += [a, b]
+            doms.append(','.join(f'{a + 1}-{b + 1}' for a, b in mine))
+        if n_dom > 1:
+            doms.append(f'1-{L}')
+        assert len(rec) <= room[p]
+        enc[enc_off[p]:enc_off[p] + len(rec)] = rec
+        expect.append(doms)
+    return lens.astype(np.int64), enc, enc_off, expect
+
+
+def test_reccut_pieces_equals_format_then_parse():
+    """dctfp_reccut_pieces (strings + piece table of a flush straight from the cutter's integers) against the two-step way it
+    replaces: reccut_format_packed -> '1-L' appended -> PieceTable (dctfp_build_pieces)."""
+    from dctdomain_amd import _lib
+    import dctdomain_amd as dd
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    lens, enc, enc_off, expect = _random_encoding(rng, 300)
+    n = len(lens)
+    piece_cap, text_cap = len(enc) // 2 + n + 1, 12 * len(enc) + 32 * n + 64
+    pieces = np.empty(piece_cap, dtype=_lib.PIECE_DTYPE)
+    text = np.empty(text_cap, dtype=np.uint8)
+    counts = np.empty(n, dtype=np.int32)
+    tl, npc, nd, nu = (ctypes.c_int64() for _ in range(4))
+    _lib.check(lib.dctfp_reccut_pieces(n, enc.ctypes.data, enc_off.ctypes.data, lens.ctypes.data, text.ctypes.data, text_cap,
+                                       ctypes.byref(tl), counts.ctypes.data, pieces.ctypes.data, piece_cap, ctypes.byref(npc),
+                                       ctypes.byref(nd), ctypes.byref(nu)), lib)
+    assert nu.value == 0
+    flat = text[:tl.value].tobytes().decode('ascii').split(';')
+    assert flat.pop() == ''
+    assert flat == [d for doms in expect for d in doms] and counts.tolist() == [len(d) for d in expect]
+    ref = dd.PieceTable(lens, expect)
+    assert ref.n_domains == nd.value and ref.keys == flat
+    got = pieces[:npc.value]
+    for f in ('row_start', 'n_rows', 'domain', 'seq'):
+        np.testing.assert_array_equal(got[f], ref.pieces[f], err_msg=f)
+    t = dd.PieceTable.from_pieces(lens, got, nd.value, flat, counts)
+    np.testing.assert_array_equal(t.owner, ref.owner)
+    np.testing.assert_array_equal(t.source, ref.source)
+    np.testing.assert_array_equal(t.lengths, ref.lengths)
+    # status -1, a truncated record and a segment past the end are left to the caller -- and only those
+    bad = enc.copy()
+    bad[enc_off[3]] = -1
+    bad[enc_off[10] + 3] = lens[10]              # last residue of protein 10's first segment: outside
+    bad[enc_off[20] + 1] = 10 ** 6               # n_segs beyond the room
+    _lib.check(lib.dctfp_reccut_pieces(n, bad.ctypes.data, enc_off.ctypes.data, lens.ctypes.data, text.ctypes.data, text_cap,
+                                       ctypes.byref(tl), counts.ctypes.data, pieces.ctypes.data, piece_cap, ctypes.byref(npc),
+                                       ctypes.byref(nd), ctypes.byref(nu)), lib)
+    assert nu.value == 3 and [p for p in range(n) if counts[p] == 0] == [3, 10, 20]
+    assert nd.value == sum(len(d) for p, d in enumerate(expect) if p not in (3, 10, 20))
+    assert lib.dctfp_reccut_pieces(n, enc.ctypes.data, enc_off.ctypes.data, lens.ctypes.data, text.ctypes.data, 10,
+                                   ctypes.byref(tl), counts.ctypes.data, pieces.ctypes.data, piece_cap, ctypes.byref(npc),
+                                   ctypes.byref(nd), ctypes.byref(nu)) != 0
+
+
+def test_reccut_room_and_domain_encoding():
+    from dctdomain_amd import _lib, reccut
+    lib = _lib.load()
+    ns = np.arange(0, 6000)
+    np.testing.assert_array_equal(reccut.reccut_room(ns), [lib.dctfp_reccut_room(int(v)) for v in ns])
+    assert reccut._encode_domains(['1-30,61-90', '31-60']).tolist() == [2, 2, 0, 29, 60, 89, 1, 30, 59]
+    assert reccut._encode_domains(['1-30', 'x-3']) is None and reccut._encode_domains([]) is None
+    assert reccut._encode_domains(['+1-30']) is None
+
+
+def test_tensor_table_helper_equals_the_attribute_reads(monkeypatch):
+    """_tensor_table.so (one C++ pass over a list of tensors) against torch's own attributes and against the Python passes it
+    replaces; entries that are no tensors are marked."""
+    import torch
+    from dctdomain_amd import _geom
+    big = torch.arange(4000 * 24, dtype=torch.float32).reshape(4000, 24)
+    ts = [big[i * 7:i * 7 + (i % 5) + 1] for i in range(300)] + [big[:10, ::2], big.t()[:3], torch.zeros(5, dtype=torch.float64),
+                                                                  torch.zeros((2, 3, 4), dtype=torch.float16), torch.zeros((0, 24))]
+    assert _geom.helper() is not None, 'dctdomain_amd/_tensor_table.so was not built (build_ext.build_tensor_table)'
+    ptrs, meta = _geom.tensor_table(ts)
+    for i, t in enumerate(ts):
+        d = t.dim()
+        assert ptrs[i] == t.data_ptr() and meta[i, 0] == d
+        assert meta[i, 1] == t.size(0) and meta[i, 3] == t.stride(0)
+        if d >= 2:
+            assert meta[i, 2] == t.size(1) and meta[i, 4] == t.stride(1)
+        assert meta[i, 5] == _geom.code_of(t)
+    assert len({int(c) for c in meta[:300, 5]}) == 1 and meta[302, 5] != meta[0, 5]
+    mixed = ts[:4] + ['x', None, np.zeros(3)]
+    p2, m2 = _geom.tensor_table(mixed)
+    assert m2[4:, 0].tolist() == [-1, -1, -1] and p2[4:].tolist() == [0, 0, 0]
+    # the Python passes fill the same table
+    monkeypatch.setattr(_geom, '_helper', None)
+    monkeypatch.setattr(_geom, '_helper_tried', True)
+    p3, m3 = _geom.tensor_table(ts)
+    np.testing.assert_array_equal(p3, ptrs)
+    np.testing.assert_array_equal(m3, meta)
+    p4, m4 = _geom.tensor_table(mixed)
+    np.testing.assert_array_equal(m4, m2)
+    np.testing.assert_array_equal(p4, p2)

@@ -222,3 +222,89 @@ def test_constant_channel_is_reported_by_the_drop_in(tmp_path, monkeypatch):
         assert not any('constant channel' in m for m in seen)
     finally:
         logging.getLogger().removeHandler(grab)
+
+
+def _embedded(lens, seed=5, dim=640):
+    import dctdomain_amd as dd
+    from dctdomain_amd.embedding import Batch, SyntheticModel
+    rng = np.random.default_rng(seed)
+    aa = np.frombuffer(b'ACDEFGHIKLMNPQRSTVWY', dtype=np.uint8)
+    dev = torch.device('cuda', 0)
+    model = SyntheticModel(dim=dim)
+    model.to_device(dev)
+    out = []
+    for i, L in enumerate(lens):
+        b = Batch([(f'p{i:04d}', aa[rng.integers(0, 20, size=int(L))].tobytes().decode())], model, dev)
+        b.embed_batch([15, 21], 500)
+        e = b.embeds[0]
+        out.append((e.pid, e.seq, e.embed, e.contacts))
+    fresh = lambda: [dd.Fingerprint(pid=p, seq=s, embed=e, contacts=c) for p, s, e, c in out]
+    return fresh
+
+
+def test_two_phase_flush_equals_the_general_path_and_the_records():
+    """The flush as make_db runs it (geometry in one pass, strings + pieces from the cutter's integers, objects laid out while the
+    kernels run) against the general path it replaced, object for object; the writer's records against both; proteins the GPU
+    cutter hands back (L > 2 048), single-domain and 30-residue proteins inside."""
+    from dctdomain_amd import make_db, reccut
+    rng = np.random.default_rng(3)
+    lens = np.clip(rng.gamma(2.2, 150.0, size=160).astype(int), 30, 1500).tolist() + [30, 31, 45, 2100, 640, 2300, 97]
+    fresh = _embedded(lens)
+    a = make_db.fingerprint_batch(fresh(), threads=4)
+    assert make_db.LAST_PATH[0] == 'flush' and sorted(reccut.LAST.host_redo) == [163, 165]
+    b = make_db._fingerprint_batch_generic(fresh(), threads=4)
+    recs = make_db.flush_records(fresh(), threads=4)
+    assert make_db.LAST_PATH[0] == 'flush'
+    recs_b = make_db._records(b)
+    n_multi = 0
+    for fa, fb, ra, rb in zip(a, b, recs, recs_b):
+        assert fa.domains == fb.domains and list(fa.quants) == list(fb.quants) == fa.domains
+        n_multi += len(fa.domains) > 1
+        for k in fa.domains:
+            assert fa.quants[k].dtype == np.int64 == fb.quants[k].dtype
+            np.testing.assert_array_equal(fa.quants[k], fb.quants[k])
+        assert ra[0] == rb[0] == fa.pid and ra[1] == rb[1] == fa.domains
+        assert ra[2].dtype == np.int8 and ra[2].shape == (len(fa.domains), 480)
+        np.testing.assert_array_equal(ra[2], rb[2])
+        np.testing.assert_array_equal(ra[2].astype(np.int64), np.array([fa.quants[k] for k in fa.domains]))
+    assert n_multi >= 100
+    np.testing.assert_array_equal(make_db._records(a)[7][2], recs[7][2])
+    # what the plain flush does not take goes the general way, with the same results: numpy inputs, domains given by the caller
+    c = fresh()
+    for fp in c[:5]:
+        fp.embed = {k: v.cpu().numpy() for k, v in fp.embed.items()}
+    c = make_db.fingerprint_batch(c, threads=4)
+    assert make_db.LAST_PATH[0] == 'generic'
+    d = fresh()
+    d[2].domains = ['1-20']
+    d = make_db.fingerprint_batch(d, threads=4)
+    assert make_db.LAST_PATH[0] == 'generic' and d[2].domains[0] == '1-20'
+    for fa, fc in zip(a, c):
+        assert fa.domains == fc.domains
+        for k in fa.domains:
+            np.testing.assert_array_equal(fa.quants[k], fc.quants[k])
+
+
+def test_process_sequences_with_deferred_second_halves_keeps_the_order():
+    """process_sequences finishes a flush when the next one has been started: the records must reach the writer in sequence order
+    and equal those of one big flush."""
+    from dctdomain_amd import make_db
+    from dctdomain_amd.embedding import SyntheticModel
+    rng = np.random.default_rng(9)
+    aa = np.frombuffer(b'ACDEFGHIKLMNPQRSTVWY', dtype=np.uint8)
+    seqs = [(f's{i:03d}', aa[rng.integers(0, 20, size=int(L))].tobytes().decode())
+            for i, L in enumerate(np.clip(rng.gamma(2.0, 120.0, size=90).astype(int), 25, 900))]
+    dev = torch.device('cuda', 0)
+    model = SyntheticModel()
+    model.to_device(dev)
+
+    def run(flush):
+        got, sizes = [], []
+        make_db.process_sequences(seqs, model, dev, 500, 4, flush, lambda recs: (got.extend(recs), sizes.append(len(recs))))
+        return got, sizes
+    small, sizes = run(16)
+    big, one = run(10 ** 6)
+    assert len(sizes) >= 4 and len(one) == 1 and [r[0] for r in small] == [p for p, _ in seqs] == [r[0] for r in big]
+    for x, y in zip(small, big):
+        assert x[1] == y[1]
+        np.testing.assert_array_equal(x[2], y[2])

@@ -25,9 +25,12 @@ ctx.set_option('degenerate_channels', 0)
 t0 = time.perf_counter()
 doms = reccut.domains_from_maps(maps, 2.6)
 dt = time.perf_counter() - t0
-v = [ctx.get_option(f'walk_timeline_{i}') for i in range(8)]
-names = ['graph', 'pre/post + forward lists', 'scans + single cut', 'double-cut scan', 'decision', 'hand-over']
-tot = sum(v[:6])
+v = [ctx.get_option(f'walk_timeline_{i}') for i in range(11)]
+names = ['graph', 'pre/post + forward lists', 'scans + single cut', 'scan: tile fills + final reduce', 'decision', 'hand-over', None, None,
+         "scan: wave 0's rows", "scan: wave 0's wait for the block's slowest wave", 'scan: tile clears']
+tot = sum(v[:6]) + sum(v[8:11])
 print(f'{n} proteins L in [{lens.min()}, {lens.max()}] mean {lens.mean():.0f}: call {1e3 * dt:.2f} ms; {v[6]} nodes, sum V^2 = {v[7]}')
 for k, nm in enumerate(names):
+    if nm is None:
+        continue
     print(f'  {nm:28s} {v[k] / 100:10.0f} us summed over proteins = {100 * v[k] / tot:5.1f} %  ({v[k] / 100 / max(1, v[6]):.2f} us per node)')

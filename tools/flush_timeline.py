@@ -30,25 +30,50 @@ torch.cuda.synchronize()
 fresh = lambda: [Fingerprint(pid=f.pid, seq=f.seq, embed=f.embed, contacts=f.contacts) for f in queue]
 make_db._records(make_db.fingerprint_batch(fresh()[:256], threads=16))
 make_db._records(make_db.fingerprint_batch(fresh(), threads=16))
-best = None
-for rep in range(5):
-    q = fresh()
-    make_db.MARKS = []
-    t0 = time.perf_counter()
-    fps = make_db.fingerprint_batch(q, threads=16)
-    t1 = time.perf_counter()
-    recs = make_db._records(fps)
-    t2 = time.perf_counter()
-    marks = make_db.MARKS + [('records', t2)]
-    make_db.MARKS = None
-    if best is None or t2 - t0 < best[0]:
-        best = (t2 - t0, marks, t0)
-dt, marks, t0 = best
-print(f'flush of {n} ({"tie-free" if smooth else "synthetic"} maps): best of 5 {1e3 * dt:.2f} ms = {1e6 * dt / n:.2f} us per protein; host redo {len(reccut.LAST.host_redo)}')
-prev = t0
-for name, t in marks:
-    print(f'  {1e3 * (t - t0):8.2f} ms  (+{1e3 * (t - prev):6.2f})  {name}')
-    prev = t
+
+
+def timed(label, fn, reps=5):
+    best = None
+    for rep in range(reps):
+        q = fresh()
+        torch.cuda.synchronize()
+        make_db.MARKS = []
+        t0 = time.perf_counter()
+        out = fn(q)
+        t2 = time.perf_counter()
+        marks = make_db.MARKS + [('end', t2)]
+        make_db.MARKS = None
+        if best is None or t2 - t0 < best[0]:
+            best = (t2 - t0, marks, t0)
+    dt, marks, t0 = best
+    print(f'{label}: best of {reps} {1e3 * dt:.2f} ms = {1e6 * dt / n:.2f} us per protein ({"tie-free" if smooth else "synthetic"} maps; '
+          f'path {make_db.LAST_PATH[0]}, host redo {len(reccut.LAST.host_redo)})')
+    prev = t0
+    for name, t in marks:
+        print(f'  {1e3 * (t - t0):8.2f} ms  (+{1e3 * (t - prev):6.2f})  {name}')
+        prev = t
+    return out
+
+
+timed(f'fingerprint_batch + _records of {n} (objects filled as queue_cpu does)', lambda q: make_db._records(make_db.fingerprint_batch(q, threads=16)))
+timed(f'flush_records of {n} (what make_db hands its writer)', lambda q: make_db.flush_records(q, threads=16))
+timed(f'general path of {n} (round 5, first half)', lambda q: make_db._records(make_db._fingerprint_batch_generic(q, threads=16)), reps=3)
+
+
+def two_halves(q):
+    fl = make_db._Flush(q, threads=16)
+    assert fl.start()
+    make_db._mark('first half done (process_sequences embeds the next proteins here)')
+    fl.cut.done.synchronize()
+    make_db._mark('-- the cutter, waited for here only to take it out of the sum below')
+    t_mid = time.perf_counter()
+    recs = fl.finish(objects=False)
+    two_halves.second = time.perf_counter() - t_mid
+    make_db.LAST_PATH[0] = 'flush'
+    return recs
+
+
+timed(f'the two halves of a flush of {n} apart (as process_sequences runs them)', two_halves)
 # the GPU's share of the same flush: the chains alone, waited for
 maps = [reccut._contact_tensor(f.contacts, len(f.seq)) for f in queue]
 for rep in range(2):
