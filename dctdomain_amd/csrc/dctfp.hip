@@ -1125,11 +1125,14 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
         // (... and it streams every job on its own: where proteins come as parts + whole protein, the fused stage A of the two
         //  kernels reads the rows once -- 3.6-4.7 against 2.1-2.3 TB/s on the c4 / c5 mixes at [5, 44] / [3, 85] / [4, 80],
         //  tools/gen_probe.py; on whole-protein batches the general kernel is 2-6 % ahead)
-        // (round 5: the general kernel has fused builds for n <= 5 -- PROST's [5, 44] / [3, 85] / [4, 80] on RecCut-shaped lists)
+        // Round 5: the general kernel has FUSED builds for n <= 5 (its walks then read the rows of a protein once, as the tuned
+        // kernel's); with them and four k-steps of stage-B fragments in flight it streams the c4 / c5 mixes at [5, 44] / [3, 85] /
+        // [4, 80] at 2.6-3.3 TB/s (2.1-2.5 before) -- and the two kernels at 3.6-5.0 (tools/gen_probe.py,
+        // profiles/r05/gen_probe_fused.txt): a flush per ~ 100-row job, its Y' slot in LDS holding the workgroups per CU down, is
+        // not how short jobs want to be run.  So such batches still go to the two kernels by default; "path" = 2 gets the fused walks.
         const bool would_fuse = ctx->opt_fuse && n_groups > 0;
-        const bool gen_can_fuse = n <= kGenFusedMaxN && ctx->opt_gen_fuse;
-        const bool use_gen = gen_slots > 0 && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 256 && gen_resident >= 8 && (!would_fuse || gen_can_fuse)));
-        const bool gen_fuse = use_gen && would_fuse && gen_can_fuse && n_jobs >= 64;
+        const bool use_gen = gen_slots > 0 && (ctx->opt_path == 2 || (ctx->opt_path == 0 && n_jobs >= 256 && gen_resident >= 8 && !would_fuse));
+        const bool gen_fuse = use_gen && would_fuse && n <= kGenFusedMaxN && gen_waves <= kGenFusedMaxWaves && ctx->opt_gen_fuse && n_jobs >= 64;
         // (a small call wants parallelism, not fewer bytes: every job on its own workgroups)
         const bool fuse = !trivial && n_groups > 0 && n_jobs >= 64 && (!use_gen || gen_fuse);
         for (int li = 0; li < ng; ++li) {

@@ -4,19 +4,24 @@
 
 namespace dctfp_host {
 
-template <typename T, int N, int VEC, bool FUSED = false>
-int launch_gen_impl(const GParams& p, LaunchError* err) {
+template <typename T, int N, int VEC, bool FUSED, int NTC>
+int launch_gen_ntc(const GParams& p, LaunchError* err) {
     static const InvTab<N> inv = make_inv<N>();
     static bool attr_set = false;
     if (!attr_set) {  // dynamic LDS above 64 KB has to be asked for, once per kernel
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&walk_gen_kernel<T, N, VEC, FUSED>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&walk_gen_kernel<T, N, VEC, FUSED, NTC>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kGenLdsBudget + 1024));
         if (e != hipSuccess) return launch_fail(err, DCTFP_ERR_HIP, "hipFuncSetAttribute(walk_gen_kernel): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((walk_gen_kernel<T, N, VEC, FUSED>), dim3(p.grid), dim3(p.waves * 64), p.lds_bytes, p.stream, p.jobs, p.jobb, p.walks, p.runs,
+    hipLaunchKernelGGL((walk_gen_kernel<T, N, VEC, FUSED, NTC>), dim3(p.grid), dim3(p.waves * 64), p.lds_bytes, p.stream, p.jobs, p.jobb, p.walks, p.runs,
                        p.pieces, p.stp, p.out, p.n_cols, p.ld, p.m, p.n_slots, inv, p.degenerate);
     return DCTFP_OK;
+}
+
+template <typename T, int N, int VEC, bool FUSED = false>
+int launch_gen_impl(const GParams& p, LaunchError* err) {   // (m <= 64: the build that holds four column groups of fragments per step)
+    return p.m <= 64 ? launch_gen_ntc<T, N, VEC, FUSED, 4>(p, err) : launch_gen_ntc<T, N, VEC, FUSED, 8>(p, err);
 }
 
 template <typename T, int VEC>

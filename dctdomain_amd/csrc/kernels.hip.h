@@ -1728,8 +1728,12 @@ __device__ inline void wave_min_max64(double& mn, double& mx) {  // over all 64 
 // part's first row (one subtraction per element feeds both sets), its own shift restored once per part from the prefix sums
 // behind the whole protein's cosine table (see walk_ab_kernel); the whole protein is then a job that streams nothing.  Builds for
 // n <= 5 (two sets of n - 1 accumulators per channel); UNROLL 4 rows in flight there, as the fused variants of the tuned kernel.
-template <typename T, int N, int VEC, bool FUSED = false>
-__global__ __launch_bounds__(1024) void walk_gen_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
+// NTC: column groups of 16 the build holds registers for (4: m <= 64, 8: m <= 128) -- the stage-B fragments of DEPTH k-steps are
+// in flight ahead of their use, NTC x 8 bytes per lane and step.
+// Launch bounds: the fused builds carry two accumulator sets (at n = 5 they spilled 20 registers per lane under the 128-register
+// budget of 16 waves); their workgroups have at most ten waves (host: gen_can_fuse), as the tuned kernel's -- 168 registers.
+template <typename T, int N, int VEC, bool FUSED = false, int NTC = 8>
+__global__ __launch_bounds__(FUSED ? 640 : 1024) void walk_gen_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
                                                          const Walk* __restrict__ walks, const Run* __restrict__ runs,
                                                          const PieceA* __restrict__ pieces,
                                                          const double* __restrict__ stp, int8_t* __restrict__ out, int n_cols,
@@ -1893,25 +1897,49 @@ __global__ __launch_bounds__(1024) void walk_gen_kernel(const JobA* __restrict__
         __builtin_amdgcn_wave_barrier();
         // ---- stage B of this job: my channels against the basis
         {
-            double acc[TILES][8];
+            double acc[TILES][NTC];
 #pragma unroll
             for (int tl = 0; tl < TILES; ++tl)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[tl][c] = 0.0;
+                for (int c = 0; c < NTC; ++c) acc[tl][c] = 0.0;
             const int i4 = lane & 3, k4 = lane >> 4;
             const int wch = wave * 64 * VEC;
             const int steps = min(16 * VEC, max(0, (n_cols - wch + 3) >> 2));   // k-steps of 4 channels that hold channels
-            const double* __restrict__ fr = stp + ((size_t)(wch >> 2) * NT) * 64 + lane;
-            for (int q = 0; q < steps; ++q) {
-                double a[TILES];
+            // The B fragments of a k-step are NT x 512 bytes per wave from L2 -- the same for every job, D x cp x 8 bytes per job in
+            // all: on ~100-row jobs as many bytes as the job's own rows.  With one step's loads issued right before their MFMAs
+            // the contraction was a chain of 16 VEC L2 round trips per job, and the general kernel streamed the c4 / c5 mixes at
+            // 2.1-2.5 TB/s whatever it read (profiles/r05/gen_probe_fused_first.txt).  DEPTH steps are now in flight ahead of their
+            // use, through a buffer descriptor (wave-uniform base and step offset: no address registers).
+            // (32 registers of fragments at most; where the accumulators leave less -- n >= 6, fused n = 5 -- fewer steps, so that nothing spills)
+            constexpr int DEPTH = N > 5 ? 1 : ((FUSED && N == 5) ? (NTC > 4 ? 1 : 2) : (NTC > 4 ? 2 : 4));
+            const __amdgpu_buffer_rsrc_t frag = wave_buffer(stp + ((size_t)(wch >> 2) * NT) * 64);
+            int fl = lane;
+            asm volatile("" : "+v"(fl));   // (keeps the lane's byte offset from being hoisted above the row stream)
+            auto fetch_b = [&](double (&b)[NTC], int q) {
 #pragma unroll
-                for (int tl = 0; tl < TILES; ++tl) a[tl] = ys[min(4 * tl + i4, N - 1) * CH + wch + 4 * q + k4];
+                for (int c = 0; c < NTC; ++c)
+                    if (c < NT) b[c] = buffer_load_raw<double, false>(frag, fl * 8, (q * NT + c) * 512);
+            };
+            double bq[DEPTH][NTC];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    if (c < NT) {
-                        const double b = fr[((size_t)q * NT + c) * 64];
+            for (int r = 0; r < DEPTH; ++r)
+                if (r < steps) fetch_b(bq[r], r);
+            for (int q0 = 0; q0 < steps; q0 += DEPTH) {
 #pragma unroll
-                        for (int tl = 0; tl < TILES; ++tl) acc[tl][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tl], b, acc[tl][c], 0, 0, 0);
+                for (int r = 0; r < DEPTH; ++r) {
+                    const int q = q0 + r;
+                    if (q < steps) {
+                        double a[TILES];
+#pragma unroll
+                        for (int tl = 0; tl < TILES; ++tl) a[tl] = ys[min(4 * tl + i4, N - 1) * CH + wch + 4 * q + k4];
+#pragma unroll
+                        for (int c = 0; c < NTC; ++c) {
+                            if (c < NT) {
+#pragma unroll
+                                for (int tl = 0; tl < TILES; ++tl) acc[tl][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tl], bq[r][c], acc[tl][c], 0, 0, 0);
+                            }
+                        }
+                        if (q + DEPTH < steps) fetch_b(bq[r], q + DEPTH);
                     }
                 }
             }
@@ -1922,7 +1950,7 @@ __global__ __launch_bounds__(1024) void walk_gen_kernel(const JobA* __restrict__
                 const int row = 4 * tl + (lane >> 4);
                 if (row < N) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
+                    for (int c = 0; c < NTC; ++c)
                         if (c < NT) pz(wave, row)[16 * c + (lane & 15)] = acc[tl][c];
                 }
             }

@@ -116,7 +116,8 @@ struct GParams {
 };
 
 constexpr size_t kGenLdsBudget = 150 * 1024;  // of the 160 KB of a CU
-constexpr int kGenFusedMaxN = 5;              // fused walks of the general kernel: two sets of n - 1 accumulators per channel
+constexpr int kGenFusedMaxN = 5;              // fused walks of the general kernel: two sets of n - 1 accumulators per channel ...
+constexpr int kGenFusedMaxWaves = 10;         // ... in builds bounded to ten waves per workgroup (168 registers)
 
 // LDS of one slot: Y'[N][CH] float64; the partial Z blocks [S][N][cp] reuse it unless a wave's columns are too few
 inline size_t gen_slot_bytes(int n, int m, int waves, int vec) {

@@ -116,6 +116,60 @@ static int other_entry_points(dctfp_ctx* ctx, std::mt19937_64& rng, int rounds, 
                 return 1;
             }
         }
+        // ---- dctfp_reccut_pieces: well-formed records of the cutter, and garbage in their place (exact-size buffers: any write past what
+        // the header promises is a report)
+        {
+            const int n_prot = uni(1, 30);
+            std::vector<int64_t> rows(n_prot), enc_off(n_prot + 1, 0);
+            for (int p = 0; p < n_prot; ++p) {
+                rows[p] = uni(0, 12) == 0 ? uni(0, 21) : uni(22, 900);
+                enc_off[p + 1] = enc_off[p] + std::max<int64_t>(uni(0, 15) == 0 ? uni(0, 3) : dctfp_reccut_room((int32_t)rows[p]), 0);
+            }
+            std::vector<int32_t> enc((size_t)std::max<int64_t>(enc_off[n_prot], 1), -1);
+            int64_t segs = 0;
+            for (int p = 0; p < n_prot; ++p) {
+                int32_t* e = enc.data() + enc_off[p];
+                const int64_t room = enc_off[p + 1] - enc_off[p];
+                const int kind = uni(0, 9);
+                if (kind == 0 || room < 4) {           // garbage
+                    for (int64_t q = 0; q < room; ++q) e[q] = uni(0, 3) == 0 ? uni(-5, 2000000) : uni(-2, 40);
+                    continue;
+                }
+                const int L = (int)std::max<int64_t>(rows[p], 1);
+                int64_t q = 1;
+                int nd = 0;
+                const int want = uni(1, 6);
+                for (int d = 0; d < want; ++d) {
+                    const int ns = uni(1, 3);
+                    if (q + 1 + 2 * ns > room) break;
+                    e[q++] = ns;
+                    for (int sg = 0; sg < ns; ++sg) {
+                        const int a = uni(0, L - 1), b2 = kind == 1 ? uni(0, L + 3) : uni(a, L - 1);   // (kind 1: some segments outside / reversed)
+                        e[q++] = a;
+                        e[q++] = b2;
+                    }
+                    ++nd;
+                    segs += ns;
+                }
+                e[0] = nd;
+            }
+            const int64_t piece_cap = uni(0, 12) == 0 ? uni(0, 3) : enc_off[n_prot] / 2 + n_prot + 1;
+            const int64_t text_cap = uni(0, 12) == 0 ? uni(0, 40) : 12 * enc_off[n_prot] + 32 * n_prot + 64;
+            std::vector<dctfp_piece> pieces((size_t)std::max<int64_t>(piece_cap, 1));
+            std::vector<char> text((size_t)std::max<int64_t>(text_cap, 1));
+            std::vector<int32_t> counts(n_prot);
+            int64_t text_len = 0, n_pieces = 0, n_dom = 0, n_undone = 0;
+            if (starve) g_fail_after = uni(0, 4);
+            const int rc = dctfp_reccut_pieces(n_prot, enc.data(), enc_off.data(), rows.data(), text.data(), text_cap, &text_len, counts.data(),
+                                               pieces.data(), piece_cap, &n_pieces, &n_dom, &n_undone);
+            g_fail_after = -1;
+            if (!ok_or_expected(rc, "dctfp_reccut_pieces")) return 1;
+            if (rc == DCTFP_OK && (n_pieces > piece_cap || text_len > text_cap || n_undone > n_prot || n_dom > n_pieces)) {
+                fprintf(stderr, "dctfp_reccut_pieces: counts beyond the buffers\n");
+                return 1;
+            }
+            (void)segs;
+        }
         // ---- contact top-k + order: short and long proteins (one workgroup / stripes), every t
         {
             const int n_prot = uni(1, 40);
@@ -405,13 +459,13 @@ int main(int argc, char** argv) {
         const int64_t out_stride = off + (uni(0, 2) == 0 ? 16 : 0);
         std::vector<int8_t> out((size_t)n_domains * out_stride);
         // ---- options
-        static const char* names[] = {"path", "fuse", "ab_run_jobs", "ab_longest_first", "workspace_mb", "overlap", "ab_group", "pack_y", "small_b_jobs", "a_waves"};
+        static const char* names[] = {"path", "fuse", "ab_run_jobs", "ab_longest_first", "workspace_mb", "overlap", "ab_group", "pack_y", "small_b_jobs", "a_waves", "gen_fuse"};
         std::vector<std::pair<const char*, int64_t>> saved;
         for (int i = 0; i < uni(0, 3); ++i) {
-            const char* nm = names[uni(0, 9)];
+            const char* nm = names[uni(0, 10)];
             int64_t v = 0, old = 0;
             if (!strcmp(nm, "path")) v = uni(0, 2);
-            else if (!strcmp(nm, "fuse") || !strcmp(nm, "pack_y")) v = uni(0, 1);
+            else if (!strcmp(nm, "fuse") || !strcmp(nm, "pack_y") || !strcmp(nm, "gen_fuse")) v = uni(0, 1);
             else if (!strcmp(nm, "ab_run_jobs")) v = (int64_t[]){0, 1, 4, 16, 64}[uni(0, 4)];
             else if (!strcmp(nm, "ab_longest_first")) v = uni(0, 2);
             else if (!strcmp(nm, "workspace_mb")) v = (int64_t[]){16, 64, 4096}[uni(0, 2)];

@@ -191,42 +191,69 @@ void emulate_stage_a(const std::string& name, dim3 grid, void** a) {
 void emulate_walk_gen(const std::string& name, dim3 grid, dim3 block, size_t shmem, void** a) {
     const JobA* jobs = *(const JobA**)a[0];
     const JobB* jobb = *(const JobB**)a[1];
-    const Run* runs = *(const Run**)a[2];
-    const PieceA* pieces = *(const PieceA**)a[3];
-    const double* stp = *(const double**)a[4];
-    int8_t* out = *(int8_t**)a[5];
-    const int n_cols = *(int*)a[6];
-    const int64_t ld = *(int64_t*)a[7];
-    const int m = *(int*)a[8];
-    const int n_slots = *(int*)a[9];
+    const Walk* walks = *(const Walk**)a[2];
+    const Run* runs = *(const Run**)a[3];
+    const PieceA* pieces = *(const PieceA**)a[4];
+    const double* stp = *(const double**)a[5];
+    int8_t* out = *(int8_t**)a[6];
+    const int n_cols = *(int*)a[7];
+    const int64_t ld = *(int64_t*)a[8];
+    const int m = *(int*)a[9];
+    const int n_slots = *(int*)a[10];
     const size_t esz = elem_size(name, "walk_gen_kernel");
-    const int n = template_int(name, "walk_gen_kernel", 0), vec = template_int(name, "walk_gen_kernel", 1);
+    // template <typename T, int N, int VEC, bool FUSED, int NTC>: ... Li<N>E Li<VEC>E Lb<FUSED>E Li<NTC>E
+    const int n = template_int(name, "walk_gen_kernel", 0), vec = template_int(name, "walk_gen_kernel", 1), ntc = template_int(name, "walk_gen_kernel", 2);
+    const bool fused = name.find("Lb1ELi") != std::string::npos;
     const int waves = (int)(block.x / 64), nt = (m + 15) / 16;
-    if (block.x % 64 || waves * 64 * vec < n_cols || n_cols % vec || n_slots < 1 || n_slots > 2 ||
+    if (block.x % 64 || waves * 64 * vec < n_cols || n_cols % vec || n_slots < 1 || n_slots > 2 || nt > ntc || (fused && (waves > 10 || n > 5)) ||
         shmem < (size_t)n_slots * ((size_t)n * waves * 64 * vec + (nt * 16 <= 64 * vec ? 0 : (size_t)waves * n * nt * 16)) * 8 + 16 || shmem > 160 * 1024) {
-        fprintf(stderr, "stub: walk_gen_kernel launch shape: %d waves x %d channels per lane for D = %d, %d slots, %zu bytes of LDS\n", waves, vec, n_cols, n_slots, shmem);
+        fprintf(stderr, "stub: walk_gen_kernel launch shape: %d waves x %d channels per lane for D = %d, m = %d (build: %d column groups, fused %d, n %d), %d slots, %zu bytes of LDS\n",
+                waves, vec, n_cols, m, ntc, (int)fused, n, n_slots, shmem);
         abort();
     }
     touch(stp, (size_t)((n_cols + 3) / 4) * nt * 64 * sizeof(double));
     ++g_walk_launches;
+    const int nk = n - 1;
     for (unsigned b = 0; b < grid.x; ++b) {
         const Run run = runs[b];
-        for (uint32_t j = 0; j < run.n_jobs; ++j) {
-            const JobA job = jobs[run.job_begin + j];
-            uint32_t rows = 0;
-            for (uint32_t p = 0; p < job.n_pieces; ++p) {
-                const PieceA pc = pieces[job.piece_begin + p];
-                if (pc.n_rows == 0 || pc.t0 != rows) { fprintf(stderr, "stub: piece table of job %u broken\n", run.job_begin + j); abort(); }
-                if (pc.ptr2) { fprintf(stderr, "stub: two-source piece sent to %s\n", name.c_str()); abort(); }
-                touch(pc.ptr, (size_t)n_cols * esz);
-                touch((const char*)pc.ptr + (size_t)(pc.n_rows - 1) * (size_t)ld * esz, (size_t)n_cols * esz);
-                touch(job.basis + (size_t)pc.t0 * (n - 1), (size_t)pc.n_rows * (n - 1) * sizeof(double));
-                rows += pc.n_rows;
+        uint32_t jn = 0;
+        const uint32_t n_walks = fused ? run.n_walks : run.n_jobs;
+        for (uint32_t wi = 0; wi < n_walks; ++wi) {
+            Walk wk{run.job_begin + wi, 1, -1, 0};
+            if (fused) wk = walks[run.walk_begin + wi];
+            const bool has_w = fused && wk.whole_job >= 0;
+            const uint32_t w_rows = has_w ? jobs[wk.whole_job].n_rows : 0;
+            const uint32_t n_walk_jobs = wk.n_parts + (has_w ? 1u : 0u);
+            for (uint32_t part = 0; part < n_walk_jobs; ++part, ++jn) {
+                const uint32_t job_id = run.job_begin + jn;      // (the kernel takes the jobs of a run in order)
+                if (fused && job_id != (part < wk.n_parts ? wk.job_begin + part : (uint32_t)wk.whole_job)) {
+                    fprintf(stderr, "stub: run %u walk %u part %u is not job %u\n", b, wi, part, job_id);
+                    abort();
+                }
+                if (part < wk.n_parts) {
+                    const JobA job = jobs[job_id];
+                    uint32_t rows = 0;
+                    for (uint32_t p = 0; p < job.n_pieces; ++p) {
+                        const PieceA pc = pieces[job.piece_begin + p];
+                        if (pc.n_rows == 0 || pc.t0 != rows) { fprintf(stderr, "stub: piece table of job %u broken\n", job_id); abort(); }
+                        if (pc.ptr2) { fprintf(stderr, "stub: two-source piece sent to %s\n", name.c_str()); abort(); }
+                        touch(pc.ptr, (size_t)n_cols * esz);
+                        touch((const char*)pc.ptr + (size_t)(pc.n_rows - 1) * (size_t)ld * esz, (size_t)n_cols * esz);
+                        touch(job.basis + (size_t)pc.t0 * nk, (size_t)pc.n_rows * nk * sizeof(double));
+                        if (has_w) {
+                            touch(job.w_basis + (size_t)pc.w0 * nk, (size_t)pc.n_rows * nk * sizeof(double));
+                            touch(job.w_basis + ((size_t)w_rows + pc.w0) * nk, ((size_t)pc.n_rows + 1) * nk * sizeof(double));  // prefix sums
+                        }
+                        rows += pc.n_rows;
+                    }
+                    if (rows != job.n_rows || (int)rows < n) { fprintf(stderr, "stub: job %u has %u rows, its pieces %u\n", job_id, job.n_rows, rows); abort(); }
+                    if (has_w) touch(job.w_ref, (size_t)n_cols * esz);
+                }
+                touch_w(out + jobb[job_id].out_off, (size_t)n * m);
+                ++g_jobs_walked;
             }
-            if (rows != job.n_rows || (int)rows < n) { fprintf(stderr, "stub: job %u has %u rows, its pieces %u\n", run.job_begin + j, job.n_rows, rows); abort(); }
-            touch_w(out + jobb[run.job_begin + j].out_off, (size_t)n * m);
-            ++g_jobs_walked;
         }
+        if (jn != run.n_jobs) { fprintf(stderr, "stub: run %u of the general kernel walks %u jobs, says %u\n", b, jn, run.n_jobs); abort(); }
     }
 }
 

@@ -145,10 +145,23 @@ def test_general_shapes_in_batches_default_dispatch(dd, name, qdim, D, dtype, lo
     assert ctx.get_option('walk_launches') - launches == (1 if one_group else 2), name
     # (b) parts + whole protein, discontinuous parts: the general kernel when asked for (by default the two kernels take such a
     # batch: their stage A reads the rows of a protein once for all of its domains)
+    # Round 5: for n <= 5 it streams such proteins as FUSED walks (rows read once, the whole protein collected beside the parts).
+    n_last, m_last = qdim[2], qdim[3]
+    tuned_last = n_last == 3 and 64 < m_last <= 80 and 512 <= D <= 2560 and dtype == np.float32     # walk_ab_kernel's own shape
+    expect_fused = 0 if tuned_last else int(n_last <= 5)
     ctx.set_option('path', 2)
     try:
         out = dd.quantize_batch(lbs, table, ctx=ctx).cpu().numpy()
         assert ctx.get_option('last_path') == 2, name
+        assert ctx.get_option('last_gen_fused') == expect_fused, name
+        if expect_fused:                      # ... and every job on its own when asked to: the same bytes
+            ctx.set_option('gen_fuse', 0)
+            try:
+                unfused = dd.quantize_batch(lbs, table, ctx=ctx).cpu().numpy()
+                assert ctx.get_option('last_path') == 2 and ctx.get_option('last_gen_fused') == 0
+            finally:
+                ctx.set_option('gen_fuse', 1)
+            np.testing.assert_array_equal(out, unfused, err_msg=f'{name}: fused vs unfused general kernel')
     finally:
         ctx.set_option('path', 0)
     for s in range(0, len(lens), 7):
@@ -193,3 +206,52 @@ def test_general_kernel_nan_inf_and_constant_channels(dd):
     for s in (0, 1, 2, 6, 139):
         q = orc.quantize([layers[0][s], layers[1][s]], doms[s], qdim)
         np.testing.assert_array_equal(out[s].astype(np.int64), q[f'1-{lens[s]}'])
+
+
+@pytest.mark.parametrize('qdim,D', [([5, 44, 5, 44], 2560), ([3, 85, 3, 85], 1280), ([4, 80, 4, 80], 640), ([2, 30, 5, 44], 1280)],
+                         ids=['5x44_D2560', '3x85_D1280', '4x80_D640', '2x30_5x44_D1280'])
+def test_fused_general_kernel_on_reccut_shaped_lists(dd, qdim, D):
+    """PROST-shaped kept sizes on RecCut-shaped domain lists (1-6 parts tiling the protein, some discontinuous, + the whole
+    protein; single-domain proteins between them) in one call: the general kernel's fused walks ("path" = 2) against the
+    two-kernel path the default dispatch still picks for such lists (it is the faster one there: profiles/r05/gen_probe_fused.txt)
+    byte for byte, and against the oracle on a sample (VERDICT r4 #6)."""
+    import torch
+    rng = np.random.default_rng(77 + D + qdim[0])
+    lens, doms = [], []
+    for s in range(420):
+        L = int(rng.integers(40, 420))
+        lens.append(L)
+        k = int(rng.integers(1, 7)) if L >= 150 else 1
+        if k == 1:
+            doms.append([f'1-{L}'])
+            continue
+        extra = rng.multinomial(L - 22 * k, np.ones(k) / k)          # parts of at least 22 rows (RecCut's Min_Size)
+        edges = [0] + np.cumsum(22 + extra).tolist()
+        assert edges[-1] == L
+        parts = [f'{a + 1}-{b}' for a, b in zip(edges[:-1], edges[1:])]
+        if k >= 3 and s % 2 == 0:
+            parts = [parts[0] + ',' + parts[-1]] + parts[1:-1]       # a discontinuous domain: head + tail
+        if s % 5 == 0:
+            parts = parts[::-1]                                       # parts in another order than along the chain
+        doms.append(parts + [f'1-{L}'])
+    layers = [[make_input('esm' if k == 0 else 'gauss', L, D, 31 * D + 2 * s + k).astype(np.float32) for s, L in enumerate(lens)]
+              for k in range(2)]
+    table = dd.PieceTable(lens, doms)
+    dev = [[torch.from_numpy(x).cuda() for x in layers[k]] for k in range(2)]
+    lbs = [dd.LayerBatch(dev[k], qdim[2 * k], qdim[2 * k + 1]) for k in range(2)]
+    ctx = dd.get_context(torch.cuda.current_device())
+    ctx.set_option('path', 2)
+    try:
+        out = dd.quantize_batch(lbs, table, ctx=ctx).cpu().numpy()
+        assert ctx.get_option('last_path') == 2 and ctx.get_option('last_gen_fused') == 1
+    finally:
+        ctx.set_option('path', 0)
+    two = dd.quantize_batch(lbs, table, ctx=ctx).cpu().numpy()
+    assert ctx.get_option('last_path') == 1 and ctx.get_option('last_gen_fused') == 0
+    np.testing.assert_array_equal(out, two)
+    row_of = np.concatenate([[0], np.cumsum([len(d) for d in doms])])
+    for s in range(0, len(lens), 9):
+        q = orc.quantize([layers[0][s], layers[1][s]], doms[s], qdim)
+        for i, (key, exp) in enumerate(q.items()):
+            assert table.keys[row_of[s] + i] == key
+            np.testing.assert_array_equal(out[row_of[s] + i].astype(np.int64), exp, err_msg=f'seq {s} (L={lens[s]}) domain {key}')

@@ -23,8 +23,9 @@ for w in (sys.argv[1:] or ['c5', 'c4', 'c3']):
         lbs = [dd.LayerBatch(x, n, m, row_offsets=offs) for x in layers]
         out = torch.empty((table.n_domains, 2 * n * m), dtype=torch.int8, device=dev)
         res, outs = {}, {}
-        for path in (1, 2):
-            ctx.set_option('path', path)
+        for path in (1, 2, 3):                  # 3: the general kernel with every job on its own (round 4's form: "gen_fuse" 0)
+            ctx.set_option('path', min(path, 2))
+            ctx.set_option('gen_fuse', 0 if path == 3 else 1)
             for _ in range(2):
                 dd.quantize_batch(lbs, table, out=out, ctx=ctx)
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -32,7 +33,10 @@ for w in (sys.argv[1:] or ['c5', 'c4', 'c3']):
                 dd.quantize_batch(lbs, table, out=out, ctx=ctx)
             torch.cuda.synchronize()
             res[path] = 5 * nbytes / (time.perf_counter() - t0) / 1e9
-            assert ctx.get_option('last_path') == path
+            assert ctx.get_option('last_path') == min(path, 2)
+            fused = ctx.get_option('last_gen_fused')
             outs[path] = out.clone()
         ctx.set_option('path', 0)
-        print(f'   [{n},{m}]  two kernels {res[1]:6.0f} GB/s   general walk kernel {res[2]:6.0f} GB/s   identical={bool((outs[1] == outs[2]).all())}', flush=True)
+        ctx.set_option('gen_fuse', 1)
+        print(f'   [{n},{m}]  two kernels {res[1]:6.0f} GB/s   general walk kernel: fused walks {res[2]:6.0f} GB/s, every job on its own {res[3]:6.0f} GB/s   '
+              f'identical={bool((outs[1] == outs[2]).all() and (outs[1] == outs[3]).all())}', flush=True)
