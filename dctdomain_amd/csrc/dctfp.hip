@@ -199,6 +199,9 @@ struct dctfp_ctx {
     int64_t opt_fuse = 1, opt_pack_y = 1;
     DevBuf scratch;  // generic idct_quant fs
     DevBuf split_ws; // partial sums of the row-split stage A (small calls)
+    uint32_t* small_tickets = nullptr;  // small_call_kernel: arrival counters, zeroed once (their last taker resets them)
+    int64_t opt_small_one = 1;          // "small_one": a small call of the production shape in ONE launch (round 5); 0 = three kernels
+    int64_t last_small_one = 0;         // read only ("last_small_one"): the last dctfp_quantize went through small_call_kernel
     // stage-A cosine tables, one per (domain length, n - 1): filled once, kept for the life of the context
     std::vector<BasisSlab> basis_slabs;
     std::unordered_map<uint64_t, double*> basis_tabs;
@@ -598,6 +601,8 @@ int dctfp_destroy(dctfp_ctx* ctx) try {
     ctx->ws.release();
     ctx->scratch.release();
     ctx->split_ws.release();
+    if (ctx->small_tickets) (void)hipFree(ctx->small_tickets);
+    ctx->small_tickets = nullptr;
     ctx->cut_ws.release();
     for (auto& kv : ctx->st_cache) {
         (void)hipFree(kv.second.dev);
@@ -646,6 +651,8 @@ int dctfp_set_option(dctfp_ctx* ctx, const char* name, int64_t value) try {
         ctx->opt_fuse = value ? 1 : 0;
     } else if (n == "gen_fuse") {
         ctx->opt_gen_fuse = value ? 1 : 0;
+    } else if (n == "small_one") {
+        ctx->opt_small_one = value ? 1 : 0;
     } else if (n == "workspace_mb") {
         if (value < 16) return fail(DCTFP_ERR_INVALID, "workspace_mb must be >= 16");
         ctx->opt_ws_mb = value;
@@ -752,6 +759,8 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) try {
     else if (n == "last_path") *value = ctx->last_path;
     else if (n == "last_gen_fused") *value = ctx->last_gen_fused;
     else if (n == "gen_fuse") *value = ctx->opt_gen_fuse;
+    else if (n == "small_one") *value = ctx->opt_small_one;
+    else if (n == "last_small_one") *value = ctx->last_small_one;
     else if (n == "walk_launches") *value = ctx->walk_launches;
     else if (n == "fuse") *value = ctx->opt_fuse;
     else if (n == "workspace_mb") *value = ctx->opt_ws_mb;
@@ -1578,6 +1587,7 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             const int n_kslabs = (g.n_cols + kSlabChannels - 1) / kSlabChannels;
             auto zpart_bytes = [&](int64_t jobs_here) { return (size_t)jobs_here * n_kslabs * n * m * sizeof(double); };
             double* zpart = nullptr;
+            bool one_launch = false;   // small_call_kernel has done stage A, stage B and the int8 rows of this chunk
             {
                 AParams ap;
                 ap.jobs = dja + j0;
@@ -1603,13 +1613,35 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
                     chunk_rows = std::max<uint32_t>(32, (chunk_rows + 31) / 32 * 32);  // 8 waves x 4 rows in flight
                     const int n_chunks = (int)((max_len_all + chunk_rows - 1) / chunk_rows);
                     const size_t partial_bytes = (size_t)jn * n_chunks * nk * ldy * sizeof(double);
-                    rc = ctx->split_ws.ensure(partial_bytes + (small_b ? zpart_bytes(jn) : 0));
+                    // (small_call_kernel keeps a 3 x 80 block per job and 256-channel slab behind the partial sums)
+                    rc = ctx->split_ws.ensure(partial_bytes + (small_b ? std::max(zpart_bytes(jn), (size_t)jn * n_slabs * 3 * 80 * sizeof(double)) : 0));
                     if (rc) return rc;
                     static const InvTab<3> inv3 = make_inv<3>();
+                    // Round 5: the three steps of a small call in ONE launch (small_call_kernel: they hand over by tickets).
+                    // n = 3, m <= 80 (five column groups of fragments per k-step in registers): the production shape.
+                    if (small_b && m <= 80 && ctx->opt_small_one) {
+                        rc = get_st_plain(ctx, st, g.n_cols);
+                        if (rc) return rc;
+                        constexpr size_t kTickets = 1024;   // jn * n_slabs < 128 here: (n_slabs + 1) counters per job
+                        if (!ctx->small_tickets) {
+                            HIP_TRY(hipMalloc((void**)&ctx->small_tickets, kTickets * sizeof(uint32_t)));
+                            HIP_TRY(hipMemset(ctx->small_tickets, 0, kTickets * sizeof(uint32_t)));
+                        }
+                        if ((size_t)jn * (n_slabs + 1) <= kTickets) {
+                            zpart = (double*)((char*)ctx->split_ws.p + partial_bytes);   // (jn x n_slabs blocks of 3 x 80: below zpart_bytes(jn))
+                            hipLaunchKernelGGL((small_call_kernel<8, 4>), dim3((unsigned)(jn * n_chunks * n_slabs)), dim3(512), 0, stream,
+                                               dja + j0, djb + j0, dpc, (double*)ctx->split_ws.p, zpart, ctx->small_tickets, (int)jn, n_chunks,
+                                               chunk_rows, g.n_cols, g.ld, ldy, n_slabs, (const double*)st->fragp, m, inv3, ctx->degenerate, out);
+                            HIP_TRY(hipGetLastError());
+                            one_launch = true;
+                        }
+                    }
+                    if (!one_launch)
                     hipLaunchKernelGGL((stage_a_split_kernel<float, 3, 4, 8, 4>), dim3((unsigned)(jn * n_chunks * n_slabs)), dim3(512), 0, stream,
                                        dja + j0, dpc, (double*)ctx->split_ws.p, n_chunks, chunk_rows, g.n_cols, g.ld, ldy, n_slabs);
                     HIP_TRY(hipGetLastError());
-                    if (small_b) {  // the slabs of stage B add the chunks and scale their channels themselves
+                    if (one_launch) {
+                    } else if (small_b) {  // the slabs of stage B add the chunks and scale their channels themselves
                         zpart = (double*)((char*)ctx->split_ws.p + partial_bytes);
                         hipLaunchKernelGGL((stage_b_slab_kernel<true>), dim3((unsigned)n_kslabs, (unsigned)jn), dim3(256), 0, stream,
                                            (const double*)nullptr, ldy, (const double*)ctx->split_ws.p, n_chunks, inv3, ctx->degenerate,
@@ -1645,7 +1677,9 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
 
             rc = prof_begin(ctx, 1, sb, &ep);
             if (rc) return rc;
-            if (ctx->opt_stage_b == 1 && !small_b) {
+            ctx->last_small_one = one_launch ? 1 : 0;
+            if (one_launch) {
+            } else if (ctx->opt_stage_b == 1 && !small_b) {
                 const int64_t rows = jn * n;
                 launch_b_mfma(st->cp / 16, packed, (unsigned)((rows + kBWaves * 16 - 1) / (kBWaves * 16)), sb, yprime, (int64_t)job_bytes, rows, ldy,
                               st->dev, djb + j0, n, m, out);

@@ -1987,6 +1987,221 @@ __global__ __launch_bounds__(FUSED ? 640 : 1024) void walk_gen_kernel(const JobA
 }
 
 // ---------------------------------------------------------------------------
+// K1s: a SMALL call -- a protein at a time, the reference's own calling pattern (src/make_db.py:29-30) -- in ONE launch (round 5).
+// Such a call is the latency of a dependent chain, not bandwidth: stage_a_split_kernel -> stage_b_slab_kernel ->
+// stage_b_finish_kernel were three launches, ~ 22 us on the GPU of a 56-us call (profiles/r05/pcie_inclusive_rate.txt).  Here the
+// same three steps hand over inside one grid, by tickets: nobody waits for anybody (a workgroup that is not the last of its group
+// to arrive is done), so no assumption about which workgroups are resident together.
+//
+//   grid   : jobs x row chunks x 256-channel slabs (as stage_a_split_kernel), 8 waves each.
+//   step 1 : every workgroup: the partial sums of its rows for its 256 channels -> `partial` (global), fence, ticket of
+//            (job, slab).
+//   step 2 : the LAST workgroup of a (job, slab) to arrive: adds the chunks in chunk order, scales its 256 channels
+//            (scale_channel<3>) into LDS, contracts them against the stage-B basis -- a wave per 32 channels, all eight k-steps of
+//            fragments in flight at once (one L2 round trip), v_mfma_f64_4x4x4, rows = the 3 resampled rows -- adds the eight
+//            waves' blocks in wave order -> `zpart` (global), fence, ticket of the job.
+//   step 3 : the LAST slab of a job to arrive: adds the slabs in slab order, scales the three rows over their m values, writes
+//            the int8 block (into pinned host memory for a one-protein call).
+// Every sum runs in a fixed order, whoever does it: the bytes do not depend on the order of arrival.  The tickets are reset by
+// their last taker; the host zeroes them once, when it allocates them.
+//   stp    : the plain basis in fragment order (host: get_st_plain), NT = cp / 16 column groups (m <= 80: NT <= 5).
+// ---------------------------------------------------------------------------
+template <int WAVES, int UNROLL>
+__global__ __launch_bounds__(WAVES * 64) void small_call_kernel(const JobA* __restrict__ jobs, const JobB* __restrict__ jobb,
+                                                                 const PieceA* __restrict__ pieces, double* __restrict__ partial,
+                                                                 double* __restrict__ zpart, uint32_t* __restrict__ tickets, int n_jobs,
+                                                                 int n_chunks, uint32_t chunk_rows, int n_cols, int64_t ld, int ldy,
+                                                                 int n_slabs, const double* __restrict__ stp, int m, InvTab<3> inv,
+                                                                 unsigned long long* __restrict__ degenerate, int8_t* __restrict__ out) {
+    typedef float T;
+    constexpr int N = 3, NK = 2, VEC = 4, NTC = 5, SLAB = 64 * VEC;
+    static_assert(WAVES == 8, "a wave per 32 channels of the slab in step 2");
+    __shared__ double red[WAVES][NK * VEC][64];      // step 1: per-wave sums; step 2: Y'[3][256] + the waves' partial blocks [8][3][80]
+    __shared__ uint32_t last_flag;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t slab = blockIdx.x % (uint32_t)n_slabs;
+    const uint32_t jc = blockIdx.x / (uint32_t)n_slabs;
+    const uint32_t chunk = jc % (uint32_t)n_chunks, job_id = jc / (uint32_t)n_chunks;
+    const int col0 = ((int)slab * 64 + lane) * VEC;
+    const int colc = (col0 < n_cols) ? col0 : 0;
+    const JobA job = jobs[job_id];
+    // ---- step 1 (stage_a_split_kernel's body)
+    {
+        const PieceA* __restrict__ pc = pieces + job.piece_begin;
+        const uint32_t lo = chunk * chunk_rows;
+        const uint32_t hi = min(job.n_rows, lo + chunk_rows);  // this workgroup's rows of the job: [lo, hi)
+        double acc[NK][VEC];
+        double ref[VEC];
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[k][v] = 0.0;
+        if (lo < hi) {
+            {
+                auto r0 = load_raw<T, VEC>(reinterpret_cast<const T*>(pc[0].ptr) + colc);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) ref[v] = raw_elem<T, VEC>(r0, v);
+            }
+            const CosTab bt = cos_tab(job.basis);
+            for (uint32_t p = 0; p < job.n_pieces; ++p) {
+                const PieceA piece = pc[p];
+                const uint32_t a = max(lo, piece.t0), b = min(hi, piece.t0 + piece.n_rows);  // job rows of this piece in the chunk
+                if (a >= b) continue;
+                const T* __restrict__ base = reinterpret_cast<const T*>(piece.ptr) + colc;
+                auto row_update = [&](const typename Raw<T, VEC>::type& x, uint32_t t) {  // t = row of the job
+                    const CosTab c = bt + (size_t)t * NK;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const double d = raw_elem<T, VEC>(x, v) - ref[v];
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) acc[k][v] = fma(c[k], d, acc[k][v]);
+                    }
+                };
+                uint32_t t = a + (uint32_t)wave;
+                for (; t + (UNROLL - 1) * WAVES < b; t += UNROLL * WAVES) {
+                    typename Raw<T, VEC>::type xv[UNROLL];
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) xv[u] = load_raw<T, VEC>(base + (size_t)(t + u * WAVES - piece.t0) * ld);
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) row_update(xv[u], t + u * WAVES);
+                }
+                for (; t < b; t += WAVES) {
+                    auto x1 = load_raw<T, VEC>(base + (size_t)(t - piece.t0) * ld);
+                    row_update(x1, t);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) red[wave][k * VEC + v][lane] = acc[k][v];
+        __syncthreads();
+        for (int cl = threadIdx.x; cl < SLAB; cl += WAVES * 64) {
+            const int ln = cl / VEC, v = cl % VEC;
+            const int col = (int)slab * SLAB + cl;
+            if (col >= ldy) continue;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                double sum = red[0][k * VEC + v][ln];
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) sum += red[w][k * VEC + v][ln];
+                store_through(&partial[((size_t)jc * NK + k) * ldy + col], sum);
+            }
+        }
+    }
+    // ---- ticket of (job, slab): the last of its n_chunks workgroups goes on
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t* __restrict__ tk = tickets + (size_t)job_id * n_slabs + slab;
+        const uint32_t t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t == (uint32_t)n_chunks - 1u;
+        if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next call)
+        last_flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last_flag == 0) return;
+    __threadfence();
+    // ---- step 2: my 256 channels of the job, scaled, against the basis
+    double* const ys = &red[0][0][0];                 // [3][SLAB]
+    double* const pzb = ys + N * SLAB;                // [WAVES][3][16 NTC]
+    static_assert((size_t)N * SLAB + (size_t)WAVES * N * 16 * NTC <= (size_t)WAVES * NK * VEC * 64, "step 2 fits the reduction buffer");
+    const int NT = (m + 15) >> 4, cp = 16 * NT;
+    const int d0 = (int)slab * SLAB;
+    if ((int)threadIdx.x < SLAB) {
+        const int d = d0 + (int)threadIdx.x;
+        double f[2] = {0.0, 0.0};
+        if (d < ldy) {
+            const double* __restrict__ pj = partial + ((size_t)job_id * n_chunks) * NK * ldy + d;
+            for (int c = 0; c < n_chunks; ++c)      // chunk order (the loads are independent: all in flight)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) f[k] += __builtin_nontemporal_load(pj + ((size_t)c * NK + k) * ldy);
+        }
+        double z[3];
+        scale_channel<3>(f, inv, d >= n_cols, z, degenerate);
+#pragma unroll
+        for (int j = 0; j < N; ++j) ys[j * SLAB + threadIdx.x] = z[j];
+    }
+    __syncthreads();
+    {
+        const int i4 = lane & 3, k4 = lane >> 4;
+        const int wch = d0 + 32 * wave;                                       // my 32 channels: k-steps wch / 4 + 0 .. 7
+        const int steps = min(8, max(0, (n_cols - wch + 3) >> 2));
+        const __amdgpu_buffer_rsrc_t frag = wave_buffer(stp + ((size_t)(wch >> 2) * NT) * 64);
+        double b[8][NTC];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int c = 0; c < NTC; ++c)
+                b[q][c] = (q < steps && c < NT) ? buffer_load_raw<double, false>(frag, lane * 8, (q * NT + c) * 512) : 0.0;
+        double acc[NTC];
+#pragma unroll
+        for (int c = 0; c < NTC; ++c) acc[c] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double a = ys[min(i4, N - 1) * SLAB + 32 * wave + 4 * q + k4];   // (a channel past D holds 0, a step past `steps` meets b = 0)
+#pragma unroll
+            for (int c = 0; c < NTC; ++c) acc[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b[q][c], acc[c], 0, 0, 0);
+        }
+        // D[i = lane >> 4][j = lane & 3] of block (lane >> 2) & 3: row lane >> 4, column 16 c + (lane & 15)
+        const int row = lane >> 4;
+        if (row < N) {
+#pragma unroll
+            for (int c = 0; c < NTC; ++c)
+                if (c < NT) pzb[((size_t)wave * N + row) * (16 * NTC) + 16 * c + (lane & 15)] = acc[c];
+        }
+    }
+    __syncthreads();
+    const int n_out = N * m;
+    double* __restrict__ zp = zpart + ((size_t)job_id * n_slabs + slab) * (N * 16 * NTC);
+    for (int o = threadIdx.x; o < N * cp; o += WAVES * 64) {
+        const int j = o / cp, c = o % cp;
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sum += pzb[((size_t)w * N + j) * (16 * NTC) + c];   // wave order
+        store_through(&zp[j * (16 * NTC) + c], sum);
+    }
+    // ---- ticket of the job: the last of its n_slabs slabs goes on
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t* __restrict__ tk = tickets + (size_t)n_jobs * n_slabs + job_id;
+        const uint32_t t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t == (uint32_t)n_slabs - 1u;
+        if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last_flag == 0) return;
+    __threadfence();
+    // ---- step 3: the slabs in slab order, per-row min-max scale, int8 (src/fingerprint.py:193-195)
+    double* const bl = ys;                            // [3][m]  (everybody is past the partial blocks: the barrier above)
+    for (int o = threadIdx.x; o < n_out; o += WAVES * 64) {
+        const int j = o / m, c = o % m;
+        const double* __restrict__ zj = zpart + (size_t)job_id * n_slabs * (N * 16 * NTC) + j * (16 * NTC) + c;
+        double sum = 0.0;
+        for (int sl = 0; sl < n_slabs; ++sl) sum += __builtin_nontemporal_load(zj + (size_t)sl * (N * 16 * NTC));
+        bl[o] = sum;
+    }
+    __syncthreads();
+    if (wave < N) {
+        const int j = wave;
+        const bool ok0 = lane < m, ok1 = lane + 64 < m;
+        const double v0 = ok0 ? bl[j * m + lane] : 0.0, v1 = ok1 ? bl[j * m + lane + 64] : 0.0;
+        double mn = fmin(ok0 ? v0 : INFINITY, ok1 ? v1 : INFINITY);
+        double mx = fmax(ok0 ? v0 : -INFINITY, ok1 ? v1 : -INFINITY);
+        const bool nan_here = (ok0 && v0 != v0) || (ok1 && v1 != v1);
+        wave_min_max64(mn, mx);
+        const bool bad = __builtin_amdgcn_ballot_w64(nan_here) != 0;   // a NaN anywhere in the row: the whole row is 0
+        const double den = mx - mn;
+        int8_t* __restrict__ o = out + jobb[job_id].out_off + (int64_t)j * m;
+        if (ok0) o[lane] = quant127(v0 - mn, den, bad);
+        if (ok1) o[lane + 64] = quant127(v1 - mn, den, bad);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Zero fill of (layer, domain) blocks whose n or m is 1: the single resampled value
 // scales to 0/0 = NaN -> 0 (golden case qdim_n1).
 // ---------------------------------------------------------------------------

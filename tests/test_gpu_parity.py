@@ -69,9 +69,9 @@ def walk_eligible(case, layers):
                                   dict(workspace_mb=16), dict(a_waves=2, a_unroll=8), dict(a_waves=1), dict(overlap=1), dict(fuse=0), dict(pack_y=0),
                                   dict(path=1), dict(path=1, fuse=0), dict(path=2, ab_unroll=4), dict(path=2, ab_unroll=6), dict(path=2, ab_unroll=8),
                                   dict(path=2, ab_group=3), dict(path=2, ab_group=4), dict(path=2), dict(path=2, ab_run_jobs=4), dict(path=2, ab_run_jobs=64),
-                                  dict(path=2, ab_run_jobs=1), dict(small_b_jobs=0), dict(path=1, small_b_jobs=1 << 20)],
+                                  dict(path=2, ab_run_jobs=1), dict(small_b_jobs=0), dict(path=1, small_b_jobs=1 << 20), dict(small_one=0)],
                          ids=['valuB', 'mfmaB', 'w8u4', 'w16u8', 'w4u4', 'smallws', 'w2u8', 'w1', 'nooverlap', 'nofuse', 'nopack',
-                              'twokernels', 'twokernels_nofuse', 'walk_u4', 'walk_u6', 'walk_u8', 'walk_g3', 'walk_g4', 'walk_forced', 'walk_run4', 'walk_run64', 'walk_run1', 'mfmaB_small_calls', 'slabB_always'])
+                              'twokernels', 'twokernels_nofuse', 'walk_u4', 'walk_u6', 'walk_u8', 'walk_g3', 'walk_g4', 'walk_forced', 'walk_run4', 'walk_run64', 'walk_run1', 'mfmaB_small_calls', 'slabB_always', 'small_calls_three_kernels'])
 def test_kernel_variants_agree_with_golden(dd, opts):
     """Every kernel configuration the dispatch can pick (and the engineering knobs can force) against the golden subset.
     The knobs live in libdctfp_experiments.so only (same kernels and dispatch as the product, -DDCTFP_EXPERIMENTS), so this
@@ -798,3 +798,56 @@ def test_walk_kernel_on_half_precision_rows(dd, tdtype):
             assert row == out.shape[0]
     finally:
         ctx.set_option('path', 0)
+
+
+def test_small_calls_in_one_launch(dd):
+    """A protein at a time -- the reference's calling pattern -- through small_call_kernel (stage A over row chunks, stage B over
+    256-channel slabs and the int8 rows handed over by tickets inside ONE launch): asserted to be the kernel that ran, bit-exact
+    against the oracle and against the three kernels it replaces, over widths that end inside a slab, kept columns below and above
+    64, domain lists with discontinuous parts, NaN / inf, and call after call on one context (the tickets must come back to zero)."""
+    import torch
+    ctx = dd.get_context(torch.cuda.current_device())
+    rng = np.random.default_rng(2024)
+    n_one = 0
+    shapes = [(500, 1280, [3, 80, 3, 80]), (500, 1280, [3, 80, 3, 80]), (129, 640, [3, 80, 3, 65]), (1999, 2560, [3, 80, 3, 80]),
+              (300, 1000, [3, 70, 3, 33]), (128, 520, [3, 16, 3, 80]), (777, 1284, [3, 80]), (256, 2048, [3, 72, 3, 72, 3, 72])]
+    for rep, (L, D, qdim) in enumerate(shapes):
+        k = len(qdim) // 2
+        layers = [make_input('esm' if i == 0 else 'gauss', L, D, 1000 * rep + i).astype(np.float32) for i in range(k)]
+        if rep == 1:      # degenerate values: the (layer, domain) blocks they touch become 0, the others must not notice
+            layers[0][7, 5] = np.nan
+            layers[1][L - 60:, 9] = np.inf
+        cuts = [int(rng.integers(130, L // 2 - 20)), int(rng.integers(L // 2 + 20, L - 130))] if L >= 400 else []
+        doms = [f'1-{L}']
+        if cuts:
+            doms = [f'1-{cuts[0]}', f'{cuts[0] + 1}-{cuts[1]}', f'1-{cuts[0] // 2},{cuts[1] + 1}-{L}', f'1-{L}']
+        want = orc.quantize(layers, doms, qdim)
+        for embed in ({i: torch.from_numpy(x).cuda() for i, x in enumerate(layers)}, {i: x for i, x in enumerate(layers)}):
+            fp = dd.Fingerprint(pid=f'small{rep}', seq='A' * L, embed=embed, domains=list(doms))
+            fp.quantize(list(qdim))
+            one = ctx.get_option('last_small_one')
+            n_one += one
+            assert one == 1, (L, D, qdim)
+            assert list(fp.quants) == list(want)
+            for key in want:
+                np.testing.assert_array_equal(fp.quants[key], want[key], err_msg=f'L={L} D={D} {qdim} {key}')
+        ctx.set_option('small_one', 0)
+        try:
+            fp3 = dd.Fingerprint(pid='three', seq='A' * L, embed={i: torch.from_numpy(x).cuda() for i, x in enumerate(layers)}, domains=list(doms))
+            fp3.quantize(list(qdim))
+            assert ctx.get_option('last_small_one') == 0
+        finally:
+            ctx.set_option('small_one', 1)
+        for key in want:
+            np.testing.assert_array_equal(fp3.quants[key], fp.quants[key])
+    assert n_one == 2 * len(shapes)
+    # a handful of proteins per call through the batch API: still one launch per layer group
+    lens = [150, 400, 260]
+    layers = [[make_input('esm', L, 1280, 50 + 3 * s + i) for s, L in enumerate(lens)] for i in range(2)]
+    table = dd.PieceTable(lens, [[f'1-{L}'] for L in lens])
+    lbs = [dd.LayerBatch([torch.from_numpy(x).cuda() for x in layers[i]], 3, 80) for i in range(2)]
+    out = dd.quantize_batch(lbs, table, ctx=ctx).cpu().numpy()
+    assert ctx.get_option('last_small_one') == 1
+    for s, L in enumerate(lens):
+        q = orc.quantize([layers[0][s], layers[1][s]], [f'1-{L}'], [3, 80, 3, 80])
+        np.testing.assert_array_equal(out[s].astype(np.int64), q[f'1-{L}'])
