@@ -200,7 +200,11 @@ struct dctfp_ctx {
     DevBuf scratch;  // generic idct_quant fs
     DevBuf split_ws; // partial sums of the row-split stage A (small calls)
     uint32_t* small_tickets = nullptr;  // small_call_kernel: arrival counters, zeroed once (their last taker resets them)
-    int64_t opt_small_one = 1;          // "small_one": a small call of the production shape in ONE launch (round 5); 0 = three kernels
+    // "small_one": 1 = a small call of the production shape in ONE launch (small_call_kernel, round 5).  Off by default: measured
+    // 86 us per one-protein call against 57 through the three kernels (profiles/r05/pcie_rate_one_launch.txt, _three_launches.txt) --
+    // what the launches cost is what the hand-over inside a grid costs too on this chip: a workgroup on another XCD sees the
+    // partial sums only through agent-scope release / acquire (L2 write-back and invalidate per workgroup) and memory-side atomics.
+    int64_t opt_small_one = 0;
     int64_t last_small_one = 0;         // read only ("last_small_one"): the last dctfp_quantize went through small_call_kernel
     // stage-A cosine tables, one per (domain length, n - 1): filled once, kept for the life of the context
     std::vector<BasisSlab> basis_slabs;

@@ -2004,6 +2004,11 @@ __global__ __launch_bounds__(FUSED ? 640 : 1024) void walk_gen_kernel(const JobA
 //            the int8 block (into pinned host memory for a one-protein call).
 // Every sum runs in a fixed order, whoever does it: the bytes do not depend on the order of arrival.  The tickets are reset by
 // their last taker; the host zeroes them once, when it allocates them.
+// OUTCOME (profiles/r05/pcie_rate_one_launch.txt against pcie_rate_three_launches.txt): bit-exact, and SLOWER -- 86 us per
+// one-protein call against 57 with the three kernels.  The eight XCDs of the chip do not share an L2: what one workgroup wrote
+// reaches a workgroup on another XCD through an agent-scope release (L2 write-back) and acquire (L2 invalidate) per workgroup
+// and step, and the tickets are memory-side atomics -- dearer than the two launch boundaries they replace, which do the same
+// once for the whole grid.  Kept behind the option "small_one" (default 0) with its parity test; the dispatch does not pick it.
 //   stp    : the plain basis in fragment order (host: get_st_plain), NT = cp / 16 column groups (m <= 80: NT <= 5).
 // ---------------------------------------------------------------------------
 template <int WAVES, int UNROLL>
@@ -2114,9 +2119,22 @@ __global__ __launch_bounds__(WAVES * 64) void small_call_kernel(const JobA* __re
         double f[2] = {0.0, 0.0};
         if (d < ldy) {
             const double* __restrict__ pj = partial + ((size_t)job_id * n_chunks) * NK * ldy + d;
-            for (int c = 0; c < n_chunks; ++c)      // chunk order (the loads are independent: all in flight)
+            // chunk order; sixteen chunks' loads in flight at a time (a loop of unknown length issued them one by one, each a round
+            // trip to where the other workgroups' write-through stores went: 16 x 2 dependent latencies in the chain of a call)
+            for (int c0 = 0; c0 < n_chunks; c0 += 16) {
+                double pv[16][NK];
 #pragma unroll
-                for (int k = 0; k < NK; ++k) f[k] += __builtin_nontemporal_load(pj + ((size_t)c * NK + k) * ldy);
+                for (int i = 0; i < 16; ++i)
+#pragma unroll
+                    for (int k = 0; k < NK; ++k)
+                        pv[i][k] = (c0 + i < n_chunks) ? __builtin_nontemporal_load(pj + ((size_t)(c0 + i) * NK + k) * ldy) : 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (c0 + i < n_chunks) {
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) f[k] += pv[i][k];
+                    }
+            }
         }
         double z[3];
         scale_channel<3>(f, inv, d >= n_cols, z, degenerate);
@@ -2181,7 +2199,14 @@ __global__ __launch_bounds__(WAVES * 64) void small_call_kernel(const JobA* __re
         const int j = o / m, c = o % m;
         const double* __restrict__ zj = zpart + (size_t)job_id * n_slabs * (N * 16 * NTC) + j * (16 * NTC) + c;
         double sum = 0.0;
-        for (int sl = 0; sl < n_slabs; ++sl) sum += __builtin_nontemporal_load(zj + (size_t)sl * (N * 16 * NTC));
+        for (int s0 = 0; s0 < n_slabs; s0 += 8) {   // slab order, eight loads in flight
+            double zv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) zv[i] = (s0 + i < n_slabs) ? __builtin_nontemporal_load(zj + (size_t)(s0 + i) * (N * 16 * NTC)) : 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (s0 + i < n_slabs) sum += zv[i];
+        }
         bl[o] = sum;
     }
     __syncthreads();

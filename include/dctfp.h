@@ -331,6 +331,9 @@ int dctfp_crash_handler(int enable);
  *   "last_path"    read only: which kernels the last dctfp_quantize launched last (1 = two kernels, 2 = walk kernel)
  *   "walk_launches" read only: walk-kernel launches of this context so far
  *   "fuse"         1 (default) = proteins given as parts + whole protein are streamed once
+ *   "small_one"    1 = a call below 128 job-slabs of the production shape (float32 rows, n = 3, m <= 80) in ONE launch
+ *                  (small_call_kernel); 0 (default) = three kernels -- the faster form on this chip (dctfp.hip).
+ *                  "last_small_one" (read only): whether the last dctfp_quantize went that way
  *   "gen_fuse"     1 (default) = ... also by the general walk kernel ("path" = 2, n <= 5, at most ten waves per workgroup);
  *                  0 = it streams every job on its own, as through round 4.  "last_gen_fused" (read only): whether the last
  *                  dctfp_quantize launched the general walk kernel with fused walks

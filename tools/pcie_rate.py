@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import dctdomain_amd as dd
 rng = np.random.default_rng(0)
+if os.environ.get('DCTFP_SMALL_ONE') == '1':          # A/B: small_call_kernel instead of the three kernels of a small call
+    dd.get_context(0).set_option('small_one', 1)
+    print('small_one = 1: small_call_kernel (one launch)')
 L, D = 500, 1280
 embeds = [{15: rng.standard_normal((L, D)).astype(np.float32), 21: rng.standard_normal((L, D)).astype(np.float32)} for _ in range(16)]
 def one(e):
