@@ -216,13 +216,13 @@ struct dctfp_ctx {
     void *trace_dev = nullptr, *trace_host = nullptr;  // instrumented build only (walk_trace)
     int64_t trace_waves = 0;
     DevBuf cut_ws;   // dctfp_reccut: adjacency lists and node stacks of a batch
-    hipStream_t cut_stream[2] = {nullptr, nullptr};   // ... its two larger size classes run beside the small one
-    hipEvent_t cut_ev[3] = {nullptr, nullptr, nullptr};
+    hipStream_t cut_stream[kCutClasses - 1] = {};   // ... its larger size classes run beside the small one
+    hipEvent_t cut_ev[kCutClasses] = {};
     int ensure_cut_streams() {
         if (cut_stream[0]) return DCTFP_OK;
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < kCutClasses - 1; ++i)
             if (hipStreamCreateWithFlags(&cut_stream[i], hipStreamNonBlocking) != hipSuccess) { cut_stream[i] = nullptr; set_err("hipStreamCreate(cut) failed"); return DCTFP_ERR_HIP; }
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < kCutClasses; ++i)
             if (hipEventCreateWithFlags(&cut_ev[i], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); return DCTFP_ERR_HIP; }
         return DCTFP_OK;
     }
@@ -635,9 +635,9 @@ int dctfp_destroy(dctfp_ctx* ctx) try {
             if (ctx->ev_b[i]) (void)hipEventDestroy(ctx->ev_b[i]);
         }
     }
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < kCutClasses; ++i)
         if (ctx->cut_ev[i]) (void)hipEventDestroy(ctx->cut_ev[i]);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kCutClasses - 1; ++i)
         if (ctx->cut_stream[i]) (void)hipStreamDestroy(ctx->cut_stream[i]);
     delete ctx;
     return DCTFP_OK;
@@ -2244,9 +2244,9 @@ int dctfp_reccut(dctfp_ctx* ctx, const int32_t* n_res, int32_t n_prot, const int
     if (n_prot == 0) return DCTFP_OK;
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_TRY(hipSetDevice(ctx->device));
-    // jobs by LDS class (512 / 1024 / 2048 residues), each class one launch; scratch: adjacency lists + node stacks
+    // jobs by LDS class (512 / 1024 / 1536 / 2048 residues), each class one launch; scratch: adjacency lists + node stacks
     std::vector<int32_t> order((size_t)n_prot);
-    int32_t count[3] = {0, 0, 0};
+    int32_t count[kCutClasses] = {};
     std::vector<uint8_t> cls((size_t)n_prot);
     size_t adj_total = 0;
     for (int32_t p = 0; p < n_prot; ++p) {
@@ -2258,9 +2258,13 @@ int dctfp_reccut(dctfp_ctx* ctx, const int32_t* n_res, int32_t n_prot, const int
         ++count[cls[(size_t)p]];
         adj_total += 2 * (size_t)nc + 6 * (size_t)std::max(n_res[p], 0);
     }
-    int32_t first[3] = {0, count[0], count[0] + count[1]};
+    int32_t first[kCutClasses];
     {
-        int32_t at[3] = {first[0], first[1], first[2]};
+        int32_t at[kCutClasses], run = 0;
+        for (int c = 0; c < kCutClasses; ++c) {
+            first[c] = at[c] = run;
+            run += count[c];
+        }
         for (int32_t p = 0; p < n_prot; ++p) order[(size_t)at[cls[(size_t)p]]++] = p;
     }
     const size_t stack_ints = (size_t)kCutStack * kCutNodeInts;
@@ -2303,15 +2307,17 @@ int dctfp_reccut(dctfp_ctx* ctx, const int32_t* n_res, int32_t n_prot, const int
     HIP_TRY(hipEventRecord(stg.ev, stream));
     stg.pending = true;
     const CutJob* d = (const CutJob*)tab.p;
-    // A class's launch lasts as long as its slowest protein (one workgroup each): the two larger classes run on streams of their
-    // own beside the small one, and the caller's stream continues after all three.
-    const bool beside = count[1] + count[2] > 0 && count[0] + (count[1] > 0 ? 1 : 0) + (count[2] > 0 ? 1 : 0) > 1;
+    // A class's launch lasts as long as its slowest protein (one workgroup each): the larger classes run on streams of their
+    // own beside the small one, and the caller's stream continues after all of them.
+    int n_used = 0;
+    for (int c = 0; c < kCutClasses; ++c) n_used += count[c] > 0 ? 1 : 0;
+    const bool beside = n_used > 1;
     if (beside) {
         rc = ctx->ensure_cut_streams();
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ctx->cut_ev[0], stream));
     }
-    for (int c = 2; c >= 0; --c) {
+    for (int c = kCutClasses - 1; c >= 0; --c) {
         if (count[c] == 0) continue;
         hipStream_t s = beside && c > 0 ? ctx->cut_stream[c - 1] : stream;
         if (s != stream) HIP_TRY(hipStreamWaitEvent(s, ctx->cut_ev[0], 0));

@@ -137,7 +137,8 @@ void launch_b_mfma(int nt, bool packed, unsigned grid, hipStream_t s, const char
 // the walk kernels (k_walk.hip, k_gen.hip)
 int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fused, bool mfma_a, LaunchError* err);
 int launch_gen(const GParams& p, int dtype, int vec, int n, LaunchError* err);
-// the domain cutter's recursion (k_reccut.hip): LDS class of a protein (0 .. 2: 512 / 1024 / 2048 residues), launch of one class
+// the domain cutter's recursion (k_reccut.hip): LDS class of a protein (0 .. 3: 512 / 1024 / 1536 / 2048 residues), launch of one class
+constexpr int kCutClasses = 4;
 int reccut_class_of(int n_res, int64_t n_contacts);
 int launch_reccut(int cls, const dctfp::CutJob* jobs, unsigned n, double cut1, double cut2, hipStream_t stream, LaunchError* err);
 

@@ -102,8 +102,8 @@ __device__ inline bool cut_better(double a, int i, int j, double b, int bi, int 
 //   idx[CAP] tmp[CAP] pos[CAP] off[CAP + 1] foff[CAP + 1] A[CAP + 1] B[CAP + 2] fwd[ECAP] + node tables
 // kCutThreads: 512 for the 512-residue class, 1024 above -- a wave per 64 columns of the top node, so that a protein's scan is one
 // pass of all its waves (with 256 threads a 1 300-residue protein took 5.7 ms on its own: the latency of one workgroup)
-template <int CAP, int ECAP, int kCutThreads, int RB>
-__global__ __launch_bounds__(kCutThreads) void reccut_kernel(const CutJob* __restrict__ jobs, double cut1, double cut2) {
+template <int CAP, int ECAP, int kCutThreads, int RB, int KMAX>
+__global__ __launch_bounds__(kCutThreads, 4 /* waves per SIMD: two 512-thread workgroups per CU, or one of 1 024 */) void reccut_kernel(const CutJob* __restrict__ jobs, double cut1, double cut2) {
     extern __shared__ int32_t lds[];
     int32_t* __restrict__ idx = lds;
     int32_t* __restrict__ tmp = idx + CAP;
@@ -118,6 +118,12 @@ __global__ __launch_bounds__(kCutThreads) void reccut_kernel(const CutJob* __res
     int32_t* __restrict__ wtot = kid + 2 * kCutNodeInts;                   // 16 wave totals of the scans
     int32_t* __restrict__ U = wtot + 32;                                   // [RB][CAP / 64 + 1]: weight of a row's edges before each column group
     uint8_t* __restrict__ M = reinterpret_cast<uint8_t*>(U + RB * (CAP / 64 + 1));   // [RB][CAP]: forward weights of a block of rows, dense
+    int32_t* __restrict__ INIT = reinterpret_cast<int32_t*>(M + RB * CAP);          // [KMAX - 1][CAP]: what the bands of the scan start from
+    int32_t* __restrict__ WT = INIT + (KMAX - 1) * CAP;                              // [KMAX - 1][waves]: wave totals of the scan over INIT
+    constexpr int RBS = RB / KMAX;                                                    // rows of a band per iteration (the tile holds RBS rows of each band)
+    // tasks (band, column group) per wave: band b holds the groups from its lowest row's on -- K NG / 2 + NG / 2 + K pairs at most
+    constexpr int SLOTS = (KMAX * (CAP / 64) / 2 + (CAP / 64) / 2 + 2 * KMAX + kCutThreads / 64 - 1) / (kCutThreads / 64);
+    static_assert(RB % KMAX == 0 && RBS % 4 == 0 && RBS * KMAX * 1 <= kCutThreads, "tile rows: RBS rows of each of KMAX bands");
     int32_t* __restrict__ misc = wtot + 16;                                // [4] status, [5] action, [6] cuts, [7] cuts1, [8] cuts2, [9] out cursor,
                                                                            // [10] n_domains, [11] stack depth
     __shared__ double red_ave[kCutThreads / 64];
@@ -370,54 +376,165 @@ __global__ __launch_bounds__(kCutThreads) void reccut_kernel(const CutJob* __res
         const bool small = sum > 0 && sum < (1 << 23);
         const float sum_f = (float)sum;
         const int j_end = V - kCutMinTerminal;   // candidates: j < j_end
-        constexpr int NG = CAP / 64, NWV = kCutThreads / 64, SLOTS = (NG + NWV - 1) / NWV;
-        int below[SLOTS], tjv[SLOTS];
+        constexpr int NG = CAP / 64, NWV = kCutThreads / 64;
+        // ---- the scan in row BANDS (round 5).  Through the first version a wave owned a 64-column group and walked all of its rows
+        // one after the other: the wave of the last group had V rows to go, the wave of the first 40, and a node took as long as
+        // its longest wave (tools/cut_timing_probe.py: wave 0 waited for the slowest one for 2.4 x its own scan; on 250-residue
+        // nodes three of eight waves had no group at all).  The rows [10, j_end - 2] are now cut into K bands of `band_rows`; a
+        // task = (band, column group), active where the band has a row below the group's last column; the tasks go round the
+        // waves, so every wave walks about the same number of rows whatever V is.  What a band needs to start from -- for column
+        // j the weight inside [top + 1, j], top = the row above the band -- comes from the forward lists: INIT[b][q] collects
+        // the weight of the edges (a, q) with a above band b's top (a row's edges go to the first band below it, LDS atomics;
+        // then a running sum over the bands), and an inclusive scan over q makes it the weight inside [top_b + 1, j].
+        const int hi_top = j_end - 2;
+        const int n_scan_rows = hi_top - kCutMinTerminal + 1;
+        int K = n_scan_rows / 16;
+        K = K < 1 ? 1 : (K > KMAX ? KMAX : K);
+        int band_rows = n_scan_rows > 0 ? (n_scan_rows + K - 1) / K : RBS;
+        band_rows = (band_rows + RBS - 1) / RBS * RBS;
+        const int n_iter = n_scan_rows > 0 ? band_rows / RBS : 0;
+        const int NGa = (j_end + 63) >> 6;   // column groups with a candidate column
+        auto band_top = [&](int b) { return hi_top - b * band_rows; };
+        auto band_low = [&](int b) { return max(kCutMinTerminal, hi_top - (b + 1) * band_rows + 1); };
+        if (KMAX > 1 && K > 1) {
+            // INIT[b - 1][q], b = 1 .. K - 1
+            for (int q = tid; q < (K - 1) * CAP; q += kCutThreads) INIT[q] = 0;
+            __syncthreads();
+            for (int a = tid; a <= hi_top; a += kCutThreads) {
+                if (a < kCutMinTerminal + 1) continue;                       // (inside [top + 1, j] means a >= top + 1 >= 11)
+                const int bb = (hi_top - a) / band_rows + 1;                  // the first band whose top lies below row a
+                if (bb >= K) continue;
+                const int e1 = foff[a] + tmp[a];
+                for (int e = foff[a]; e < e1; ++e) {
+                    const uint32_t ent = fwd[e];
+                    atomicAdd(&INIT[(bb - 1) * CAP + (int)(ent & 0xffffu)], (int)(ent >> 16));
+                }
+            }
+            __syncthreads();
+            // running sum over the bands (an edge above band bb is above every later band), then the scan over q of all bands at once
+            {
+                constexpr int PER = (CAP + kCutThreads - 1) / kCutThreads;
+                int carry[KMAX > 1 ? KMAX - 1 : 1];
+#pragma unroll
+                for (int b = 0; b < KMAX - 1; ++b) carry[b] = 0;
+#pragma unroll
+                for (int m = 0; m < PER; ++m) {
+                    const int q = m * kCutThreads + tid;
+                    int x[KMAX > 1 ? KMAX - 1 : 1];
+                    int run = 0;
+#pragma unroll
+                    for (int b = 0; b < KMAX - 1; ++b) {
+                        run += (b < K - 1 && q < V) ? INIT[b * CAP + q] : 0;
+                        x[b] = run;
+                    }
+#pragma unroll
+                    for (int off2 = 1; off2 < 64; off2 <<= 1) {
+#pragma unroll
+                        for (int b = 0; b < KMAX - 1; ++b) {
+                            const int up = __shfl_up(x[b], off2);
+                            x[b] += lane >= off2 ? up : 0;
+                        }
+                    }
+                    if (lane == 63) {
+#pragma unroll
+                        for (int b = 0; b < KMAX - 1; ++b) WT[b * NWV + wave] = x[b];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int b = 0; b < KMAX - 1; ++b) {
+                        int before = carry[b], total = 0;
+                        for (int w = 0; w < NWV; ++w) {
+                            const int t_w = WT[b * NWV + w];
+                            before += w < wave ? t_w : 0;
+                            total += t_w;
+                        }
+                        if (b < K - 1 && q < V) INIT[b * CAP + q] = x[b] + before;
+                        carry[b] += total;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        // tasks: band b holds the groups g_lo(b) .. NGa - 1; task tau -> (b, g) by the running counts
+        int n_tasks = 0;
+        int cum[KMAX + 1];
+#pragma unroll
+        for (int b = 0; b < KMAX; ++b) {
+            cum[b] = n_tasks;
+            if (b < K && n_scan_rows > 0 && band_top(b) >= kCutMinTerminal) {
+                const int g_lo = (band_low(b) + 1) >> 6;
+                n_tasks += max(0, NGa - g_lo);
+            }
+        }
+        cum[KMAX] = n_tasks;
+        int task_b[SLOTS], task_g[SLOTS], below[SLOTS];
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
-            below[sl] = 0;
-            const int j = (wave + sl * NWV) * 64 + lane;
-            tjv[sl] = j < j_end ? A[j] : 0;
+            const int tau = wave + sl * NWV;
+            int b = -1, g = 0;
+            if (tau < n_tasks) {
+#pragma unroll
+                for (int bb = 0; bb < KMAX; ++bb)
+                    if (tau >= cum[bb] && tau < cum[bb + 1]) {
+                        b = bb;
+                        g = ((band_low(bb) + 1) >> 6) + tau - cum[bb];
+                    }
+            }
+            task_b[sl] = b;
+            task_g[sl] = g;
+            const int j = g * 64 + lane;
+            below[sl] = (b >= 1 && j < j_end) ? INIT[(b - 1) * CAP + j] : 0;
+        }
+        if (n_tasks > SLOTS * NWV) {   // (cannot happen: SLOTS is sized for the largest node of the class)
+            if (tid == 0) out[0] = -1;
+            return;
         }
         float best_f = 2.0f * 1.0001f;
-        for (int hi = j_end - 2; hi >= kCutMinTerminal; hi -= RB) {
-            const int n_rows = min(RB, hi - kCutMinTerminal + 1);   // rows hi, hi - 1, ... (t = 0 ..)
-            // Tile row t = row hi - t, filled by FPR threads (entry e of the row by thread e mod FPR: the byte into M, its weight
-            // added to the row's per-group total H[t][group]) and emptied again by the same threads after the scan -- tile and
-            // totals are all zero between blocks and between nodes, nothing is cleared wholesale.  (One thread per row walked
-            // its list through dependent LDS round trips: 3-4 us per block of rows, more than the rows' scan itself.)
-            constexpr int FPR = kCutThreads / RB >= 8 ? 8 : kCutThreads / RB;
-            if (tid < n_rows * FPR) {
-                const int t_row = tid / FPR, row = hi - t_row;
-                const int e1 = foff[row] + tmp[row];
-                for (int e = foff[row] + tid % FPR; e < e1; e += FPR) {
+        for (int it = 0; it < n_iter; ++it) {
+            // Tile row (b, t) = row band_top(b) - it RBS - t, filled by FPR threads (entry e of the row by thread e mod FPR: the byte
+            // into M, its weight added to the row's per-group total U[.][group]) and emptied again by the same threads after the
+            // scan -- tile and totals are all zero between iterations and between nodes, nothing is cleared wholesale.
+            constexpr int FPR = kCutThreads / (KMAX * RBS) >= 8 ? 8 : kCutThreads / (KMAX * RBS);
+            const int fill_t = tid / FPR, fill_b = fill_t / RBS;
+            int fill_row = -1;
+            if (fill_b < K) {
+                const int r = band_top(fill_b) - it * RBS - (fill_t % RBS);
+                if (r >= band_low(fill_b)) fill_row = r;
+            }
+            if (fill_row >= 0) {
+                const int e1 = foff[fill_row] + tmp[fill_row];
+                for (int e = foff[fill_row] + tid % FPR; e < e1; e += FPR) {
                     const uint32_t ent = fwd[e];
                     const int q = (int)(ent & 0xffffu);
-                    M[t_row * CAP + q] = (uint8_t)(ent >> 16);
-                    atomicAdd(&U[t_row * (NG + 1) + (q >> 6)], (int)(ent >> 16));
+                    M[fill_t * CAP + q] = (uint8_t)(ent >> 16);
+                    atomicAdd(&U[fill_t * (NG + 1) + (q >> 6)], (int)(ent >> 16));
                 }
             }
             __syncthreads();
             CUT_T(3);    // tile fill + its barrier
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
-                const int g = wave + sl * NWV;
+                const int b = task_b[sl], g = task_g[sl];
+                if (b < 0) continue;
+                const int hi = band_top(b) - it * RBS;                       // rows hi, hi - 1, ... (t = 0 ..) of this band
+                const int n_rows = min(RBS, hi - band_low(b) + 1);
                 const int g0 = g * 64;
-                if (g0 >= j_end || g0 + 63 < kCutMinTerminal + kCutMinSize - 1 || g0 + 63 <= hi - n_rows + 1) continue;   // (no candidate column / all
-                // columns of the group at or before every row of the block: nothing to add)
+                if (n_rows <= 0 || g0 + 63 <= hi - n_rows + 1) continue;     // (band done / all columns of the group at or before every row: nothing to add)
                 const int j = g0 + lane;
                 const bool col_ok = j < j_end;
-                const int tj = tjv[sl];
+                const int tj = col_ok ? A[j] : 0;
+                const int tr0 = b * RBS;                                     // my band's rows of the tile
                 int m_u = 0;   // lane t: weight of row hi - t's edges before this group's first column
                 if (lane < n_rows)
-                    for (int k = 0; k < g; ++k) m_u += U[lane * (NG + 1) + k];
+                    for (int k = 0; k < g; ++k) m_u += U[(tr0 + lane) * (NG + 1) + k];
                 const int m_c = lane < n_rows ? B[hi - lane] : 0;
                 int bl = below[sl];
-                static_assert(RB % 4 == 0, "rows go through four at a time");
+                static_assert(RBS % 4 == 0, "rows go through four at a time");
                 for (int t = 0; t < n_rows; t += 4) {   // four rows at a time: their scans and tests are independent chains
                     int x[4], ns2[4], cv[4], ns1[4];
                     bool maybe[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) x[k] = (int)M[(t + k) * CAP + j];   // (rows past the block's last: zero)
+                    for (int k = 0; k < 4; ++k) x[k] = (int)M[(tr0 + t + k) * CAP + j];   // (rows past the band's last: zero)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         // inclusive scan over the wave's 64 lanes: four steps inside the 16-lane rows, two across them
@@ -469,16 +586,15 @@ __global__ __launch_bounds__(kCutThreads) void reccut_kernel(const CutJob* __res
             CUT_T(8);    // this wave's rows
             __syncthreads();   // (every wave has read the tile)
             CUT_T(9);    // the wait for the slowest wave of the block
-            if (tid < n_rows * FPR) {
-                const int t_row = tid / FPR, row = hi - t_row;
-                const int e1 = foff[row] + tmp[row];
-                for (int e = foff[row] + tid % FPR; e < e1; e += FPR) {
+            if (fill_row >= 0) {
+                const int e1 = foff[fill_row] + tmp[fill_row];
+                for (int e = foff[fill_row] + tid % FPR; e < e1; e += FPR) {
                     const int q = (int)(fwd[e] & 0xffffu);
-                    M[t_row * CAP + q] = 0;
-                    U[t_row * (NG + 1) + (q >> 6)] = 0;
+                    M[fill_t * CAP + q] = 0;
+                    U[fill_t * (NG + 1) + (q >> 6)] = 0;
                 }
             }
-            // (the next block's fill by the same threads follows without a barrier only for their own entries: a barrier for the rest)
+            // (the next iteration's fill by the same threads follows without a barrier only for their own entries: a barrier for the rest)
             __syncthreads();
             CUT_T(10);   // tile cleared
         }
@@ -722,8 +838,9 @@ __global__ __launch_bounds__(kCutThreads) void reccut_kernel(const CutJob* __res
     }
 }
 
-constexpr size_t reccut_lds_bytes(int cap, int ecap, int rb) {
-    return ((size_t)7 * cap + 8 + ecap + 3 * kCutNodeInts + 32 + (size_t)rb * (cap / 64 + 1)) * 4 + (size_t)rb * cap;
+constexpr size_t reccut_lds_bytes(int cap, int ecap, int rb, int kmax, int threads) {
+    return ((size_t)7 * cap + 8 + ecap + 3 * kCutNodeInts + 32 + (size_t)rb * (cap / 64 + 1)) * 4 + (size_t)rb * cap +
+           ((size_t)(kmax - 1) * cap + (size_t)(kmax > 1 ? kmax - 1 : 1) * (threads / 64)) * 4;
 }
 
 }  // namespace dctfp

@@ -271,14 +271,15 @@ def test_gpu_reccut_goldens():
 @pytest.mark.gpu
 def test_gpu_reccut_fuzz_against_host_library():
     """4 000 random graphs (blocks, interleaved blocks, tie-rich weights, contacts inside the band, L = 22 .. 700, a few up to
-    1 500) through both: identical strings; the host library itself is held to the reference's binary by the tests above."""
+    1 500 and up to 2 048) through both: identical strings; the host library itself is held to the reference's binary by the tests above."""
     from dctdomain_amd import reccut
     rng = np.random.default_rng(777)
     n_multi = n_disc = n_total = 0
     for batch in range(8):
         n_res, offs, ci, cj, cv = [], [0], [], [], []
         for k in range(500):
-            L = int(rng.integers(22, 700)) if k % 50 else int(rng.integers(700, 1500))
+            # (every LDS class of the kernel: 512 / 1 024 / 1 536 / 2 048 residues; its scan runs in 1 .. 4 row bands by node size)
+            L = int(rng.integers(22, 700)) if k % 50 else (int(rng.integers(700, 1500)) if k % 100 else int(rng.integers(1500, 2049)))
             ii, jj, pv = _random_graph(rng, L)
             n_res.append(L); ci.append(ii); cj.append(jj); cv.append(pv); offs.append(offs[-1] + len(ii))
         args = (n_res, offs, np.concatenate(ci), np.concatenate(cj), np.concatenate(cv))
