@@ -211,8 +211,10 @@ class CutInFlight:
     encoded results on their way into a page-locked buffer: what a database flush starts early and picks up when it needs
     the domains (``make_db._Flush``).  ``ptrs`` / ``lds`` / ``n_res``: the contact maps' geometry (``_geom.tensor_table``)."""
 
-    def __init__(self, ptrs, lds, n_res, device, t: float, cut1=CUT1_DEFAULT, cut2=CUT2_DEFAULT, stream=None, slot: int = 0):
+    def __init__(self, ptrs, lds, n_res, device, t: float, cut1=CUT1_DEFAULT, cut2=CUT2_DEFAULT, stream=None, slot: int = 0,
+                 timing: bool = False):
         lib = _lib.load()
+        self.events = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timing else None    # (tools/flush_timeline.py)
         n = len(n_res)
         self.n = n
         self.n_res = np.ascontiguousarray(n_res, dtype=np.int32)
@@ -233,9 +235,13 @@ class CutInFlight:
             on = torch.zeros(n, dtype=torch.int32, device=device)
             ctx = _lib.get_context(device.index)
             sp = C.c_void_p(self.stream.cuda_stream)
+            if timing:
+                self.events[0].record(self.stream)
             _lib.check(lib.dctfp_contact_topk(ctx.handle, ptrs.ctypes.data, lds.ctypes.data, self.n_res.ctypes.data, n, float(t),
                                               self.oi.data_ptr(), self.oj.data_ptr(), self.ov.data_ptr(), self.offs.ctypes.data,
                                               on.data_ptr(), sp), lib)
+            if timing:
+                self.events[1].record(self.stream)
             room = reccut_room(self.n_res)
             self.enc_off = np.zeros(n + 1, dtype=np.int64)
             np.cumsum(room, out=self.enc_off[1:])
@@ -243,10 +249,14 @@ class CutInFlight:
             enc = torch.empty(n_enc, dtype=torch.int32, device=device)
             _lib.check(lib.dctfp_reccut(ctx.handle, self.n_res.ctypes.data, n, self.oi.data_ptr(), self.oj.data_ptr(), self.ov.data_ptr(),
                                         self.offs.ctypes.data, self.cut1, self.cut2, enc.data_ptr(), self.enc_off.ctypes.data, sp), lib)
+            if timing:
+                self.events[2].record(self.stream)
             self.penc = _pinned(f'enc{slot}', torch.int32, n_enc)
             self.penc.copy_(enc, non_blocking=True)
             self.pn = _pinned(f'n{slot}', torch.int32, n)
             self.pn.copy_(on, non_blocking=True)
+            if timing:
+                self.events[3].record(self.stream)
             self.done = torch.cuda.Event()
             self.done.record(self.stream)
         self._keep = (enc, on)
@@ -255,6 +265,9 @@ class CutInFlight:
         """The encoded results (host view, valid until this thread's next batch in the same slot); proteins the GPU cutter
         handed back (status -1) are redone by the host library here and written into the same encoding."""
         self.done.synchronize()
+        if self.events is not None:
+            e = self.events
+            LAST.gpu_ms = (e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[2].elapsed_time(e[3]))   # top-k, cutter, copies
         if not (self.pn.numpy() == self.counts).all():
             raise RuntimeError('dctfp_contact_topk wrote a different number of contacts than dctfp_contact_count says')
         enc = self.penc.numpy()

@@ -48,6 +48,9 @@ def timed(label, fn, reps=5):
     dt, marks, t0 = best
     print(f'{label}: best of {reps} {1e3 * dt:.2f} ms = {1e6 * dt / n:.2f} us per protein ({"tie-free" if smooth else "synthetic"} maps; '
           f'path {make_db.LAST_PATH[0]}, host redo {len(reccut.LAST.host_redo)})')
+    if getattr(reccut.LAST, 'gpu_ms', None) and make_db.LAST_PATH[0] == 'flush':
+        g = reccut.LAST.gpu_ms
+        print(f'  on the GPU (events on the side stream): contact top-k {g[0]:.2f} ms, cutter {g[1]:.2f} ms, results to the host {g[2]:.2f} ms')
     prev = t0
     for name, t in marks:
         print(f'  {1e3 * (t - t0):8.2f} ms  (+{1e3 * (t - prev):6.2f})  {name}')
