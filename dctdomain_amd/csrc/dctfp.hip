@@ -220,8 +220,15 @@ struct dctfp_ctx {
     hipEvent_t cut_ev[kCutClasses] = {};
     int ensure_cut_streams() {
         if (cut_stream[0]) return DCTFP_OK;
+        // (the highest priority the device offers: what runs on them -- the long proteins' workgroups, the striped selection -- is
+        //  what a flush waits for, and its workgroups should take the CUs the short proteins' ones leave)
+        int prio_low = 0, prio_high = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) {
+            (void)hipGetLastError();
+            prio_high = 0;
+        }
         for (int i = 0; i < kCutClasses - 1; ++i)
-            if (hipStreamCreateWithFlags(&cut_stream[i], hipStreamNonBlocking) != hipSuccess) { cut_stream[i] = nullptr; set_err("hipStreamCreate(cut) failed"); return DCTFP_ERR_HIP; }
+            if (hipStreamCreateWithPriority(&cut_stream[i], hipStreamNonBlocking, prio_high) != hipSuccess) { cut_stream[i] = nullptr; set_err("hipStreamCreate(cut) failed"); return DCTFP_ERR_HIP; }
         for (int i = 0; i < kCutClasses; ++i)
             if (hipEventCreateWithFlags(&cut_ev[i], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); return DCTFP_ERR_HIP; }
         return DCTFP_OK;
@@ -2120,6 +2127,19 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
     HIP_TRY(hipEventRecord(stg.ev, stream));
     stg.pending = true;
     const TopkJob* djobs = (const TopkJob*)tab.p;
+    // The selection of the long proteins (stripes: four histogram passes, the collection, the ties) and that of the short ones
+    // (one workgroup each: one read, what it hands back, ...) touch different proteins: they run side by side -- the long chain on
+    // a stream of its own, forked here (the tables are up) and joined before the caller's stream goes on.  A flush of 2 048
+    // proteins spent 2.8 ms in the two chains one after the other, 0.9 ms of kernels each and a dozen launch gaps
+    // (profiles/r05/flush_kernel_stats_tiefree.txt).
+    const bool long_beside = n_long > 0 && used_stripes > 0 && n_short > 0;
+    const hipStream_t short_stream = stream;
+    if (long_beside) {
+        rc = ctx->ensure_cut_streams();
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ctx->cut_ev[0], stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->cut_stream[0], ctx->cut_ev[0], 0));
+    }
     if (n_short > 0) {
         if (ctx->opt_topk_kernel != 1) {   // one read of the map (0; 2 = straight to the two-read kernel of round 4); what a kernel hands
             // back (out_n = -1) the next one redoes: the two-read kernel, then the radix select
@@ -2141,6 +2161,7 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
         }
         HIP_TRY(hipGetLastError());
     }
+    if (long_beside) stream = ctx->cut_stream[0];
     if (n_long > 0 && used_stripes > 0) {
         const TopkJob* dlong = djobs + n_short;
         const TopkStripe* dstripes = (const TopkStripe*)((char*)tab.p + off_stripe);
@@ -2156,6 +2177,11 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
         hipLaunchKernelGGL(topk_ties_kernel, dim3((unsigned)used_stripes), dim3(64), 0, stream, dlong, dstripes, dstate, dties, dfirst,
                            out_i, out_j, out_v);
         HIP_TRY(hipGetLastError());
+    }
+    if (long_beside) {
+        HIP_TRY(hipEventRecord(ctx->cut_ev[1], stream));
+        stream = short_stream;
+        HIP_TRY(hipStreamWaitEvent(stream, ctx->cut_ev[1], 0));
     }
     return mark_table_used(ctx, buf, stream);
 } DCTFP_GUARD("dctfp_contact_topk")
@@ -2317,7 +2343,10 @@ int dctfp_reccut(dctfp_ctx* ctx, const int32_t* n_res, int32_t n_prot, const int
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ctx->cut_ev[0], stream));
     }
-    for (int c = kCutClasses - 1; c >= 0; --c) {
+    // (the small class first: its many short workgroups fill the chip three per CU and drain within a few hundred microseconds; the
+    //  long classes, on high-priority streams, take the CUs as they come free.  The other way round the 80-155 KB workgroups of the
+    //  long classes held the LDS of most CUs and the small class ran in what was left: 3.3 ms for kernels of 1.8 / 1.7 / 0.8 ms)
+    for (int c = 0; c < kCutClasses; ++c) {
         if (count[c] == 0) continue;
         hipStream_t s = beside && c > 0 ? ctx->cut_stream[c - 1] : stream;
         if (s != stream) HIP_TRY(hipStreamWaitEvent(s, ctx->cut_ev[0], 0));

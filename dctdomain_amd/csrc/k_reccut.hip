@@ -32,11 +32,12 @@ int reccut_class_of(int n_res, int64_t n_contacts) {
 
 int launch_reccut(int cls, const dctfp::CutJob* jobs, unsigned n, double cut1, double cut2, hipStream_t stream, LaunchError* err) {
     if (n == 0) return DCTFP_OK;
-    // (class: residues, threads, rows of the byte tile, bands of the scan -- the LDS holds KMAX - 1 start vectors of CAP ints)
+    // (class: residues, threads, rows of the byte tile, bands of the scan -- KMAX - 2 start vectors of CAP ints of LDS beside the
+    //  one that lives in `pos`: 49 / 80 / 119 / 155 KB per workgroup, i.e. three / two / one / one per CU)
     if (cls == 0) return launch_class<512, 512, 32, 4>(jobs, n, cut1, cut2, stream, err);
     if (cls == 1) return launch_class<1024, 1024, 16, 4>(jobs, n, cut1, cut2, stream, err);
-    if (cls == 2) return launch_class<1536, 1024, 16, 4>(jobs, n, cut1, cut2, stream, err);   // (125 KB of LDS: four bands still fit; at 2 048 two)
-    return launch_class<2048, 1024, 16, 2>(jobs, n, cut1, cut2, stream, err);
+    if (cls == 2) return launch_class<1536, 1024, 16, 4>(jobs, n, cut1, cut2, stream, err);
+    return launch_class<2048, 1024, 16, 4>(jobs, n, cut1, cut2, stream, err);   // (155 KB of LDS)
 }
 
 }  // namespace dctfp_host

@@ -118,8 +118,11 @@ __global__ __launch_bounds__(kCutThreads, 4 /* waves per SIMD: two 512-thread wo
     int32_t* __restrict__ wtot = kid + 2 * kCutNodeInts;                   // 16 wave totals of the scans
     int32_t* __restrict__ U = wtot + 32;                                   // [RB][CAP / 64 + 1]: weight of a row's edges before each column group
     uint8_t* __restrict__ M = reinterpret_cast<uint8_t*>(U + RB * (CAP / 64 + 1));   // [RB][CAP]: forward weights of a block of rows, dense
-    int32_t* __restrict__ INIT = reinterpret_cast<int32_t*>(M + RB * CAP);          // [KMAX - 1][CAP]: what the bands of the scan start from
-    int32_t* __restrict__ WT = INIT + (KMAX - 1) * CAP;                              // [KMAX - 1][waves]: wave totals of the scan over INIT
+    // what the bands of the scan start from, [KMAX - 1][CAP]: band 1's vector lives in `pos` (nobody reads pos between the forward
+    // lists and the end of the node, where it is reset -- wholesale then), the others behind the tile
+    int32_t* __restrict__ INITX = reinterpret_cast<int32_t*>(M + RB * CAP);
+    auto INIT = [&](int b) -> int32_t* { return b == 0 ? pos : INITX + (b - 1) * CAP; };   // b = band - 1
+    int32_t* __restrict__ WT = INITX + (KMAX > 2 ? KMAX - 2 : 0) * CAP;              // [KMAX - 1][waves]: wave totals of the scan over the vectors
     constexpr int RBS = RB / KMAX;                                                    // rows of a band per iteration (the tile holds RBS rows of each band)
     // tasks (band, column group) per wave: band b holds the groups from its lowest row's on -- K NG / 2 + NG / 2 + K pairs at most
     constexpr int SLOTS = (KMAX * (CAP / 64) / 2 + (CAP / 64) / 2 + 2 * KMAX + kCutThreads / 64 - 1) / (kCutThreads / 64);
@@ -398,7 +401,8 @@ __global__ __launch_bounds__(kCutThreads, 4 /* waves per SIMD: two 512-thread wo
         auto band_low = [&](int b) { return max(kCutMinTerminal, hi_top - (b + 1) * band_rows + 1); };
         if (KMAX > 1 && K > 1) {
             // INIT[b - 1][q], b = 1 .. K - 1
-            for (int q = tid; q < (K - 1) * CAP; q += kCutThreads) INIT[q] = 0;
+            for (int b = 0; b < K - 1; ++b)
+                for (int q = tid; q < V; q += kCutThreads) INIT(b)[q] = 0;
             __syncthreads();
             for (int a = tid; a <= hi_top; a += kCutThreads) {
                 if (a < kCutMinTerminal + 1) continue;                       // (inside [top + 1, j] means a >= top + 1 >= 11)
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(kCutThreads, 4 /* waves per SIMD: two 512-thread wo
                 const int e1 = foff[a] + tmp[a];
                 for (int e = foff[a]; e < e1; ++e) {
                     const uint32_t ent = fwd[e];
-                    atomicAdd(&INIT[(bb - 1) * CAP + (int)(ent & 0xffffu)], (int)(ent >> 16));
+                    atomicAdd(&INIT(bb - 1)[(int)(ent & 0xffffu)], (int)(ent >> 16));
                 }
             }
             __syncthreads();
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(kCutThreads, 4 /* waves per SIMD: two 512-thread wo
                     int run = 0;
 #pragma unroll
                     for (int b = 0; b < KMAX - 1; ++b) {
-                        run += (b < K - 1 && q < V) ? INIT[b * CAP + q] : 0;
+                        run += (b < K - 1 && q < V) ? INIT(b)[q] : 0;
                         x[b] = run;
                     }
 #pragma unroll
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(kCutThreads, 4 /* waves per SIMD: two 512-thread wo
                             before += w < wave ? t_w : 0;
                             total += t_w;
                         }
-                        if (b < K - 1 && q < V) INIT[b * CAP + q] = x[b] + before;
+                        if (b < K - 1 && q < V) INIT(b)[q] = x[b] + before;
                         carry[b] += total;
                     }
                     __syncthreads();
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(kCutThreads, 4 /* waves per SIMD: two 512-thread wo
             task_b[sl] = b;
             task_g[sl] = g;
             const int j = g * 64 + lane;
-            below[sl] = (b >= 1 && j < j_end) ? INIT[(b - 1) * CAP + j] : 0;
+            below[sl] = (b >= 1 && j < j_end) ? INIT(b - 1)[j] : 0;
         }
         if (n_tasks > SLOTS * NWV) {   // (cannot happen: SLOTS is sized for the largest node of the class)
             if (tid == 0) out[0] = -1;
@@ -789,6 +793,8 @@ __global__ __launch_bounds__(kCutThreads, 4 /* waves per SIMD: two 512-thread wo
         __syncthreads();
         CUT_T(4);   // decision
         const int action = misc[5];
+        for (int p = tid; p < V; p += kCutThreads) pos[p] = -1;       // (band 1's start vector sat in pos[0 .. V))
+        __syncthreads();
         for (int p = tid; p < V; p += kCutThreads) pos[ix[p]] = -1;
         if (action < 0) {
             if (tid == 0) out[0] = -1;
@@ -840,7 +846,7 @@ __global__ __launch_bounds__(kCutThreads, 4 /* waves per SIMD: two 512-thread wo
 
 constexpr size_t reccut_lds_bytes(int cap, int ecap, int rb, int kmax, int threads) {
     return ((size_t)7 * cap + 8 + ecap + 3 * kCutNodeInts + 32 + (size_t)rb * (cap / 64 + 1)) * 4 + (size_t)rb * cap +
-           ((size_t)(kmax - 1) * cap + (size_t)(kmax > 1 ? kmax - 1 : 1) * (threads / 64)) * 4;
+           ((size_t)(kmax > 2 ? kmax - 2 : 0) * cap + (size_t)(kmax > 1 ? kmax - 1 : 1) * (threads / 64)) * 4;
 }
 
 }  // namespace dctfp
