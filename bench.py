@@ -431,6 +431,97 @@ def measure(args, wl, steps, warmup, env):
     return res
 
 
+def measure_pipeline(args, steps, env, n_prot: int = 2048, D: int = 2560):
+    """BASELINE config 4 AS STATED -- "L x L contact-map (L <= 500) + RecCut domain split, per-domain fingerprint, D = 2560" -- as
+    make_db runs a flush of it (make_db.flush_records): contact top-k (dctfp_contact_topk) -> the domain cutter's recursion
+    (dctfp_reccut) -> strings + piece table (dctfp_reccut_pieces) -> dctfp_quantize -> (pid, domains, int8 rows) on the host.  Inputs
+    (two embedding layers and the contact map per protein) resident in HBM; a step = one flush of `n_prot` proteins, in one piece
+    (the wait for the cutter inside).  Parity sample: the CPU chain oracle top-k -> the reference's RecCut binary (oracle/_ref,
+    when it is there) -> oracle quantize."""
+    np, torch, dd, device = env['np'], env['torch'], env['dd'], env['device']
+    from dctdomain_amd import make_db, reccut
+    rng = np.random.default_rng(4242)
+    lens = rng.integers(100, 501, size=n_prot).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(99)
+    layers = [make_layer(torch, gen, int(offs[-1]), D, device) for _ in range(2)]
+    maps = []
+    for L in lens.tolist():       # a decaying band + blocks of 90-150 residues that contact inside themselves: what RecCut cuts along
+        i = torch.arange(L, device=device)
+        blk = int(rng.integers(90, 151))
+        near = 0.9 * torch.exp(-(i[:, None] - i[None, :]).abs().float() / 12.0)
+        u = torch.rand((L, L), generator=gen, device=device)
+        cm = near + 0.3 * u * ((i[:, None] // blk) == (i[None, :] // blk)) + 0.02 * torch.rand((L, L), generator=gen, device=device)
+        maps.append((0.5 * (cm + cm.t())).clamp_(0, 1).contiguous())
+    seqs = ['A' * int(L) for L in lens]
+
+    def fresh():
+        return [dd.Fingerprint(pid=f'p{s:05d}', seq=seqs[s], embed={15: layers[0][offs[s]:offs[s + 1]], 21: layers[1][offs[s]:offs[s + 1]]},
+                               contacts=maps[s]) for s in range(n_prot)]
+    for _ in range(2):
+        recs = make_db.flush_records(fresh(), threads=16)
+    path = make_db.LAST_PATH[0]
+    batches = [fresh() for _ in range(steps)]
+    # (the inputs of ALL steps exist before the loop -- steps x n_prot objects with their dicts: park them where the cyclic collector
+    #  does not walk them every time a flush's own few thousand containers trip it; a build holds two flushes' worth, not ten)
+    import gc
+    gc.collect()
+    gc.freeze()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for b in batches:
+        recs = make_db.flush_records(b, threads=16)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    gc.unfreeze()
+    make_db.MARKS = []                     # one more flush with the GPU's own times (events on the side stream) and the host marks
+    recs = make_db.flush_records(fresh(), threads=16)
+    marks, make_db.MARKS = make_db.MARKS, None
+    gpu_ms = getattr(reccut.LAST, 'gpu_ms', None)
+    at = {name: t for name, t in marks}
+    n_fp = sum(len(r[1]) for r in recs)
+    # ---- parity sample (checker only, outside the timed region)
+    parity = None
+    if args.parity_sample > 0:
+        from oracle import contacts_oracle as co
+        from oracle import dct_oracle as orc
+        have_ref = os.path.exists(co.REF_BIN)
+        bad_dom = bad_fp = checked = doms_checked = 0
+        for s in np.linspace(0, n_prot - 1, min(args.parity_sample, 32)).astype(int):
+            pid, doms, rows8 = recs[s]
+            L = int(lens[s])
+            if have_ref:
+                ci, cj, cv = co.top_contacts(maps[s].cpu().numpy(), 2.6)
+                rc, out_txt = co.run_ref_binary(co.ce_text(pid, seqs[s], ci, cj, cv), pid)
+                bad_dom += int(rc != 0 or co.parse_reccut(out_txt, L) != doms)
+                doms_checked += 1
+            q = orc.quantize([x[offs[s]:offs[s + 1]].cpu().numpy() for x in layers], doms, [3, 80, 3, 80])
+            for k, key in enumerate(q):
+                bad_fp += int(np.any(rows8[k].astype(np.int64) != q[key]))
+                checked += 1
+        parity = {'checked': checked, 'mismatching_fingerprints': bad_fp, 'domain_lists_checked_against_the_reference_binary': doms_checked,
+                  'mismatching_domain_lists': bad_dom}
+    res = {
+        'value': n_fp * steps / elapsed, 'unit': 'fingerprints/s', 'proteins_per_s': n_prot * steps / elapsed,
+        'us_per_protein': 1e6 * elapsed / (steps * n_prot), 'ms_per_step': 1e3 * elapsed / steps, 'steps': steps,
+        'config': {'workload': f'C4 as stated: {n_prot} proteins per flush, L ~ U[100,500], per protein an L x L contact map (synthetic: band + '
+                               f'90-150-residue blocks) -> top {2.6} L contacts -> RecCut -> per-domain + whole-protein fingerprints from 2 layers of '
+                               f'D={D} float32, qdim [3,80]x2; {n_fp} fingerprints per flush; make_db.flush_records (path: {path})',
+                   'proteins_per_flush': n_prot, 'fingerprints_per_flush': n_fp, 'D': D, 'layers': 2},
+        'gpu_ms': None if not gpu_ms else {'contact_topk': round(gpu_ms[0], 3), 'domain_cutter': round(gpu_ms[1], 3)},
+        'host_ms': None if 'cutter waited for' not in at else {
+            'first_half': round(1e3 * (at['embedding tables'] - at['start']), 3),
+            'wait_for_the_cutter': round(1e3 * (at['cutter waited for'] - at['embedding tables']), 3),
+            'second_half': round(1e3 * (at['results on the host'] - at['cutter waited for']), 3)},
+        'roofline': None,      # (a latency chain -- a few long recursions, one workgroup each -- not a stream: DESIGN section 5)
+        'parity': parity,
+    }
+    del layers, maps, batches
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -498,10 +589,14 @@ def main():
     if world == 1 and want != 'none':
         others = {}
         for wl in want.split(','):
+            if wl == 'c4_pipeline':
+                continue
             r = measure(args, wl, args.extra_steps, 2, env)
             if r is not None:
                 others[wl] = {'value': r['value'], 'unit': 'fingerprints/s', 'ms_per_step': r['ms_per_step'], 'steps': r['steps'],
                               'config': r['config'], 'roofline': r['roofline'], 'host_table_ms': r['host_table_ms'], 'parity': r['parity']}
+        if args.workloads == 'auto' or 'c4_pipeline' in args.workloads.split(','):
+            others['c4_pipeline'] = measure_pipeline(args, args.extra_steps, env)
 
     if rank == 0:
         line = {
