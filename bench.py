@@ -64,8 +64,10 @@ def parse():
                          'region starts from already stitched matrices (rounds 1-4; not BASELINE config 3 as stated)')
     ap.add_argument('--workloads', default='auto',
                     help='N = 1 only: further workloads measured after the headline and reported in the line\'s "workloads" object '
-                         '(auto = c3,c4,c5 behind the default c2 run, none otherwise; "none"; or a comma list)')
+                         '(auto = c3,c4,c5,c4_pipeline behind the default c2 run, none otherwise; "none"; or a comma list; c4_pipeline = '
+                         'BASELINE config 4 as stated: contact map -> top-k -> RecCut -> per-domain fingerprints at D = 2560)')
     ap.add_argument('--extra-steps', type=int, default=10, help='timed steps of each of those workloads (warm-up 2)')
+    ap.add_argument('--pipeline-proteins', type=int, default=2048, help='proteins per flush of the c4_pipeline workload')
     return ap.parse_args()
 
 
@@ -596,7 +598,7 @@ def main():
                 others[wl] = {'value': r['value'], 'unit': 'fingerprints/s', 'ms_per_step': r['ms_per_step'], 'steps': r['steps'],
                               'config': r['config'], 'roofline': r['roofline'], 'host_table_ms': r['host_table_ms'], 'parity': r['parity']}
         if args.workloads == 'auto' or 'c4_pipeline' in args.workloads.split(','):
-            others['c4_pipeline'] = measure_pipeline(args, args.extra_steps, env)
+            others['c4_pipeline'] = measure_pipeline(args, args.extra_steps, env, n_prot=args.pipeline_proteins)
 
     if rank == 0:
         line = {

@@ -220,13 +220,17 @@ class _Flush:
         _mark('strings + piece table')
         total = sum(l.n_keep * l.m_keep for l in self.layers)
         self.ctx.get_option('degenerate_seen')  # (the flag is the context's: drop what earlier callers left unread)
-        out = quantize_batch(self.layers, table, ctx=self.ctx)
-        stream = torch.cuda.current_stream(self.device)
-        pin = getattr(_PINNED, 'buf', None)
-        if pin is None or pin.numel() < nd * total:
-            pin = _PINNED.buf = torch.empty(max(nd * total + nd * total // 4, 1 << 20), dtype=torch.int8, pin_memory=True)
-        view = pin[:nd * total].view(nd, total)
-        view.copy_(out, non_blocking=True)
+        # On the flush's own stream, not the caller's: inside a build the caller's stream still holds the language model's kernels for
+        # the NEXT proteins, and this flush's embeddings were complete before its cutter started (which waited for the caller's stream,
+        # and has been waited for above) -- the fingerprint kernel runs beside them instead of behind them.
+        stream = self.cut.stream
+        with torch.cuda.stream(stream):
+            out = quantize_batch(self.layers, table, ctx=self.ctx)
+            pin = getattr(_PINNED, 'buf', None)
+            if pin is None or pin.numel() < nd * total:
+                pin = _PINNED.buf = torch.empty(max(nd * total + nd * total // 4, 1 << 20), dtype=torch.int8, pin_memory=True)
+            view = pin[:nd * total].view(nd, total)
+            view.copy_(out, non_blocking=True)
         _mark('quantize enqueued')
         # ---- everything that needs only the SHAPE of the result, while the kernels run
         bounds = np.zeros(n + 1, dtype=np.int64)

@@ -92,3 +92,20 @@ def test_traffic_stamp_matches_the_kernel_sources():
         pytest.fail(msg)
     for w in ('c2', 'c4', 'c5'):
         assert tj['workloads'][w]['kernel'] == 'walk_ab_kernel' and tj['workloads'][w]['hbm_bytes_per_launch'] > 0
+
+
+@pytest.mark.gpu
+def test_pipeline_workload_in_the_line():
+    """workloads.c4_pipeline (BASELINE config 4 as stated: contact map -> top-k -> RecCut on the GPU -> fingerprints at D = 2560): in
+    the line, through the two-phase flush, its parity sample -- incl. the domain lists against the reference's binary where
+    oracle/_ref is built -- clean."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--n-seq', '600', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0',
+                        '--parity-sample', '6', '--workloads', 'c4_pipeline', '--extra-steps', '2', '--pipeline-proteins', '192'],
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    w = line['workloads']['c4_pipeline']
+    assert 'path: flush' in w['config']['workload'] and w['config']['proteins_per_flush'] == 192
+    assert w['value'] > 0 and w['us_per_protein'] > 0 and w['gpu_ms']['domain_cutter'] > 0
+    assert w['parity']['checked'] >= 6 and w['parity']['mismatching_fingerprints'] == 0 and w['parity']['mismatching_domain_lists'] == 0
+    assert line['parity']['mismatching_fingerprints'] == 0
