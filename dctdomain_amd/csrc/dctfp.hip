@@ -928,6 +928,9 @@ struct PieceSrc {
     int64_t b, row_b;
 };
 
+// Set by dctfp_quantize_one around its dctfp_quantize: the caller waits for the stream before anything else can touch the context.
+thread_local bool tl_sync_call = false;
+
 // dctfp_quantize proper.  `out_row` (optional): the output row of every domain of THIS piece table (a call that
 // dctfp_quantize has split in two); without it domain d writes row d.  `src` (optional, one per piece; n_data = windows):
 // see PieceSrc -- pieces, seq_rows and seq then speak of the STITCHED sequences.  The caller holds the context's mutex.
@@ -1720,13 +1723,17 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             const int64_t used = std::min<int64_t>(c, slots);
             for (int64_t k = 0; k < used; ++k) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_b[k], 0));
         }
-        HIP_TRY(hipEventRecord(ctx->ev_ws_free, stream));  // ... and the scratch is free for the next call after this point
-        ctx->ws_busy = true;
-        HIP_TRY(hipEventRecord(ctx->ev_tab_free[buf], stream));  // this table buffer may be overwritten after this point
-        ctx->tab_busy[buf] = true;
-        if (zero_copy) {
-            HIP_TRY(hipEventRecord(stg.ev, stream));
-            stg.pending = true;
+        // (dctfp_quantize_one waits for the stream before it returns: scratch, tables and staging buffer ARE free for whoever
+        //  comes next, on whatever stream -- three event records, 4-5 us of a 56-us call, say nothing it does not already know)
+        if (!tl_sync_call) {
+            HIP_TRY(hipEventRecord(ctx->ev_ws_free, stream));  // ... and the scratch is free for the next call after this point
+            ctx->ws_busy = true;
+            HIP_TRY(hipEventRecord(ctx->ev_tab_free[buf], stream));  // this table buffer may be overwritten after this point
+            ctx->tab_busy[buf] = true;
+            if (zero_copy) {
+                HIP_TRY(hipEventRecord(stg.ev, stream));
+                stg.pending = true;
+            }
         }
         l0 = l1;
     }
@@ -1926,8 +1933,13 @@ int dctfp_quantize_one(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_laye
         std::lock_guard<std::mutex> lock(ctx->mu);
         if (ctx->flag_host) __atomic_store_n(ctx->flag_host, 0u, __ATOMIC_RELEASE);
     }
+    tl_sync_call = true;
     rc = dctfp_quantize(ctx, layers, n_layers, 1, &n_rows, pieces.data(), n_pieces, *n_domains, out, out_stride, stream_v);
-    if (rc) return rc;
+    tl_sync_call = false;
+    if (rc) {
+        (void)hipStreamSynchronize(stream);   // (whatever was enqueued before the failure must not outlive the buffers it reads)
+        return rc;
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     if (degenerate_seen && ctx->flag_host) *degenerate_seen = (int32_t)__atomic_exchange_n(ctx->flag_host, 0u, __ATOMIC_ACQ_REL);
     return DCTFP_OK;
