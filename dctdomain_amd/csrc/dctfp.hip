@@ -60,6 +60,9 @@ struct DevBuf {
     int ensure(size_t bytes) {
         if (bytes <= cap) return DCTFP_OK;
         if (p) {
+            // (growth is rare; kernels of ANOTHER stream may still be reading the old block -- a flush's cutter on its side stream --
+            //  and hipFree is only known to wait for the blocking streams)
+            (void)hipDeviceSynchronize();
             hipError_t e = hipFree(p);  // device-synchronising: earlier launches are done with it
             p = nullptr;
             cap = 0;
@@ -102,7 +105,10 @@ struct Staging {  // pinned host buffer + the event after its last H2D copy (or 
             if (e != hipSuccess) return fail(DCTFP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
         }
         if (bytes <= cap) return DCTFP_OK;
-        if (p) (void)hipHostFree(p);
+        if (p) {
+            (void)hipDeviceSynchronize();   // (a kernel reading the tables straight from this buffer, on whatever stream)
+            (void)hipHostFree(p);
+        }
         p = nullptr;
         dev = nullptr;
         cap = 0;
@@ -1725,7 +1731,9 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
         }
         // (dctfp_quantize_one waits for the stream before it returns: scratch, tables and staging buffer ARE free for whoever
         //  comes next, on whatever stream -- three event records, 4-5 us of a 56-us call, say nothing it does not already know)
-        if (!tl_sync_call) {
+        // -- for the LAST layer group of the call only: an earlier group's buffers are taken again by a later group of the same call
+        // (five layers of five geometries: the staging buffer of group 1 is group 3's), long before the call's wait.
+        if (!(tl_sync_call && l1 == n_layers)) {
             HIP_TRY(hipEventRecord(ctx->ev_ws_free, stream));  // ... and the scratch is free for the next call after this point
             ctx->ws_busy = true;
             HIP_TRY(hipEventRecord(ctx->ev_tab_free[buf], stream));  // this table buffer may be overwritten after this point
@@ -2012,6 +2020,9 @@ int dctfp_gather_rows(dctfp_ctx* ctx, const void* embed, int32_t dtype, int64_t 
     }
     rc = tab.ensure((size_t)n_pieces * sizeof(PieceA));
     if (rc) return rc;
+    // (the table buffer may still be read by kernels another stream runs -- a flush's cutter on its side stream while the caller's
+    //  stream stitches the next proteins: overwrite it only behind them)
+    if (ctx->tab_busy[buf]) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_free[buf], 0));
     HIP_TRY(hipMemcpyAsync(tab.p, stg.p, (size_t)n_pieces * sizeof(PieceA), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(stg.ev, stream));
     stg.pending = true;
@@ -2135,6 +2146,9 @@ int dctfp_contact_topk(dctfp_ctx* ctx, const void* const* maps, const int64_t* l
     const int64_t used_stripes = s_fill;  // (a stripe can come out empty when rows are long: it is simply not emitted)
     rc = tab.ensure(all_bytes);
     if (rc) return rc;
+    // (the table buffer may still be read by kernels another stream runs -- a flush's cutter on its side stream while the caller's
+    //  stream stitches the next proteins: overwrite it only behind them)
+    if (ctx->tab_busy[buf]) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_free[buf], 0));
     HIP_TRY(hipMemcpyAsync(tab.p, stg.p, up_bytes, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(stg.ev, stream));
     stg.pending = true;
@@ -2341,6 +2355,9 @@ int dctfp_reccut(dctfp_ctx* ctx, const int32_t* n_res, int32_t n_prot, const int
         j.out_cap = (int32_t)std::min<int64_t>(out_offs[p + 1] - out_offs[p], 0x7fffffff);
         j.reserved = 0;
     }
+    // (the table buffer may still be read by kernels another stream runs -- a flush's cutter on its side stream while the caller's
+    //  stream stitches the next proteins: overwrite it only behind them)
+    if (ctx->tab_busy[buf]) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_free[buf], 0));
     HIP_TRY(hipMemcpyAsync(tab.p, stg.p, (size_t)n_prot * sizeof(CutJob), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(stg.ev, stream));
     stg.pending = true;
@@ -2439,6 +2456,9 @@ int stitch_impl(dctfp_ctx* ctx, const dctfp_stitch_job* jobs, int64_t n_jobs, in
         o.reserved = 0;
         max_rows[(size_t)level] = std::max(max_rows[(size_t)level], j.n_rows);
     }
+    // (the table buffer may still be read by kernels another stream runs -- a flush's cutter on its side stream while the caller's
+    //  stream stitches the next proteins: overwrite it only behind them)
+    if (ctx->tab_busy[buf]) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tab_free[buf], 0));
     HIP_TRY(hipMemcpyAsync(tab.p, stg.p, (size_t)n_jobs * sizeof(StitchJob), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(stg.ev, stream));
     stg.pending = true;

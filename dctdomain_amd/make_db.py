@@ -515,11 +515,13 @@ def process_sequences(seqs, model, device, maxlen: int, cpu: int, flush: int, si
     def flush_queue():
         q = list(queue)
         queue.clear()
+        # (the flush before this one first: its fingerprint kernel goes onto the side stream, and behind this flush's cutter it would
+        #  wait for exactly the latency the two halves are apart to avoid)
+        finish_pending()
         with stage('fingerprint (contact top-k + RecCut + dctfp_quantize)'):
             fl = _Flush(q, threads=cpu)
             if not fl.start():
                 fl = None
-        finish_pending()
         pending.append((fl, q))
 
     for pid, seq in seqs:                          # same packing rule as Database.yield_seqs
