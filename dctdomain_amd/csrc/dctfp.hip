@@ -224,6 +224,8 @@ struct dctfp_ctx {
     DevBuf cut_ws;   // dctfp_reccut: adjacency lists and node stacks of a batch
     hipStream_t cut_stream[kCutClasses - 1] = {};   // ... its larger size classes run beside the small one
     hipEvent_t cut_ev[kCutClasses] = {};
+    hipEvent_t ev_cut_ws_free = nullptr;            // after the last dctfp_reccut that used cut_ws (calls on different streams share it)
+    bool cut_ws_busy = false;
     int ensure_cut_streams() {
         if (cut_stream[0]) return DCTFP_OK;
         // (the highest priority the device offers: what runs on them -- the long proteins' workgroups, the striped selection -- is
@@ -650,6 +652,7 @@ int dctfp_destroy(dctfp_ctx* ctx) try {
     }
     for (int i = 0; i < kCutClasses; ++i)
         if (ctx->cut_ev[i]) (void)hipEventDestroy(ctx->cut_ev[i]);
+    if (ctx->ev_cut_ws_free) (void)hipEventDestroy(ctx->ev_cut_ws_free);
     for (int i = 0; i < kCutClasses - 1; ++i)
         if (ctx->cut_stream[i]) (void)hipStreamDestroy(ctx->cut_stream[i]);
     delete ctx;
@@ -2323,6 +2326,9 @@ int dctfp_reccut(dctfp_ctx* ctx, const int32_t* n_res, int32_t n_prot, const int
     const size_t ws_bytes = align_up(adj_total * sizeof(uint32_t), 16) + (size_t)n_prot * stack_ints * sizeof(int32_t);
     int rc = ctx->cut_ws.ensure(ws_bytes);
     if (rc) return rc;
+    // (adjacency lists and node stacks are the context's: a call on another stream waits for the kernels of the last one)
+    if (!ctx->ev_cut_ws_free) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_cut_ws_free, hipEventDisableTiming));
+    if (ctx->cut_ws_busy) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream_v, ctx->ev_cut_ws_free, 0));
     const int buf = ctx->flip;
     Staging& stg = ctx->staging[buf];
     DevBuf& tab = ctx->tables[buf];
@@ -2391,6 +2397,8 @@ int dctfp_reccut(dctfp_ctx* ctx, const int32_t* n_res, int32_t n_prot, const int
             HIP_TRY(hipStreamWaitEvent(stream, ctx->cut_ev[c], 0));
         }
     }
+    HIP_TRY(hipEventRecord(ctx->ev_cut_ws_free, stream));
+    ctx->cut_ws_busy = true;
     return mark_table_used(ctx, buf, stream);
 } DCTFP_GUARD("dctfp_reccut")
 

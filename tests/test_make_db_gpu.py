@@ -308,3 +308,39 @@ def test_process_sequences_with_deferred_second_halves_keeps_the_order():
     for x, y in zip(small, big):
         assert x[1] == y[1]
         np.testing.assert_array_equal(x[2], y[2])
+
+
+def test_cutter_in_flight_while_the_callers_stream_uses_the_context():
+    """The first half of a flush leaves its contact selection and cutter running on a side stream; the caller's stream goes on using
+    the SAME context -- window stitching (job tables in the context's double-buffered table block), another domain prediction
+    (the cutter's adjacency scratch), a fingerprint call.  Every one of them must queue behind the readers of what it overwrites
+    (a build once did not: stitch_impl uploaded its table over the cutter's) -- the flush's results must be
+    those of the flush run alone."""
+    from dctdomain_amd import make_db, reccut
+    from dctdomain_amd.embedding import stitch_embeddings_batch, stitch_contacts_batch
+    rng = np.random.default_rng(12)
+    lens = np.clip(rng.gamma(2.2, 170.0, size=700).astype(int), 60, 1300).tolist()
+    fresh = _embedded(lens, seed=8)
+    alone = make_db.flush_records(fresh(), threads=4)
+    dev = torch.device('cuda', 0)
+    wins = [[torch.randn(500, 640, device=dev), torch.randn(350, 640, device=dev)] for _ in range(3)]
+    cwins = [[torch.rand(500, 500, device=dev), torch.rand(400, 400, device=dev)]]
+    other = [fp.contacts for fp in fresh()[:40]]
+    other_alone = reccut.domains_from_maps(other, 2.6)
+    for rep in range(3):
+        fl = make_db._Flush(fresh(), threads=4)
+        assert fl.start()
+        # ... the caller's stream, while the cutter runs: both table buffers several times over, the cutter's scratch, a quantize
+        for _ in range(4):
+            stitch_embeddings_batch(wins)
+            stitch_contacts_batch(cwins, 300)
+        assert reccut.domains_from_maps(other, 2.6) == other_alone
+        few = make_db.flush_records(fresh()[:8], threads=2)
+        recs = fl.finish(objects=False)
+        assert recs is not None and len(recs) == len(alone)
+        for a, b in zip(alone, recs):
+            assert a[0] == b[0] and a[1] == b[1]
+            np.testing.assert_array_equal(a[2], b[2])
+        for a, b in zip(alone[:8], few):
+            assert a[1] == b[1]
+            np.testing.assert_array_equal(a[2], b[2])
