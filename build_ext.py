@@ -44,7 +44,7 @@ UNITS = ['dctfp.hip', 'k_walk.hip', 'k_gen.hip', 'k_reccut.hip', 'k_stage_b.hip'
          'k_stage_a_bf16.hip']
 TWIN_UNITS = ('dctfp.hip', 'k_walk.hip')
 HEADERS = [os.path.join(CSRC, 'kernels.hip.h'), os.path.join(CSRC, 'launch.h'), os.path.join(ROOT, 'include', 'dctfp.h'),
-           os.path.join(CSRC, 'reccut_kernel.hip.h')]
+           os.path.join(CSRC, 'reccut_kernel.hip.h'), os.path.join(CSRC, 'k_stage_a.inc')]
 OBJ_DIR = os.path.join(ROOT, 'build', 'dctfp_objs')
 
 
