@@ -100,6 +100,8 @@ LAST_PATH = [None]
 
 _SEQ, _CONTACTS, _EMBED, _DOMAINS, _QUANTS, _PID = (_attrgetter(a) for a in ('seq', 'contacts', 'embed', 'domains', 'quants', 'pid'))
 _SIDE_STREAMS = {}
+#: which of the two sets of page-locked result buffers the next flush takes (two flushes are alive at a time in process_sequences: the one
+#: whose cutter runs and the one being finished; the buffers themselves are per thread, reccut._pinned)
 _FLUSH_SLOT = [0]
 
 
@@ -274,6 +276,10 @@ class _Flush:
             logging.info('\n'.join(f'{now} Fingerprinted {fp.pid}' for fp in fps))
         self.cut = None
         return result
+
+
+#: the two halves of a flush for callers outside this module
+Flush = _Flush
 
 
 def _lib_mod():
