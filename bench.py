@@ -384,7 +384,7 @@ def measure(args, wl, steps, warmup, env):
         # of the kernel sources it was measured on; a stamp that does not match the sources of THIS run means the number is
         # stale -> null, never a silently outdated constant.
         # (the walk kernel of the reference's shape, the general walk kernel for every other shape of float32 / float64 rows)
-        tuned_shape = qn == 3 and 64 < qm <= 80 and 512 <= D <= 2560 and D % 4 == 0
+        tuned_shape = qn == 3 and 64 < qm <= (96 if args.storage == 'float32' else 80) and 512 <= D <= 2560 and D % 4 == 0
         kernel = ('walk_ab_kernel' if tuned_shape else 'walk_gen_kernel') if last_path == 2 else 'stage_a_kernel'
         traffic, traffic_note = None, 'no PMC measurement for this workload / source state'
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')

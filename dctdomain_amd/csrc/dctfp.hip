@@ -244,6 +244,7 @@ struct dctfp_ctx {
     int64_t opt_path = 0, opt_ab_group = 0, opt_ab_unroll = 0, opt_ab_run_jobs = 0, opt_small_b_jobs = 512, opt_ab_longest_first = 0, opt_ab_mfma_a = 0, opt_ab_taper = 4, opt_ab_align = 2, opt_l1_kernel = 0, opt_row_select = 0, opt_stitch_once = 0, opt_topk_kernel = 0;
     int64_t last_path = 0;  // which kernels the last dctfp_quantize launched: 1 = stage A + stage B, 2 = walk kernel
     int64_t last_gen_fused = 0;  // ... and whether that was the general walk kernel streaming fused walks (parts + whole protein)
+    int64_t last_walk_groups = 0;  // ... or walk_ab_kernel: its build's 16-column groups (5: m <= 80, 6: 80 < m <= 96), 0 = another kernel
     int64_t opt_gen_fuse = 1;    // "gen_fuse": fused walks through the general walk kernel (n <= 5); 0 = the two kernels, as through round 4
     int64_t walk_launches = 0;  // walk-kernel launches so far (a call split at a giant domain ends on the two-kernel path)
     int64_t test_fail_once = 0;                    // test hook: the next dctfp_quantize fails after its table lookups
@@ -345,14 +346,15 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
     HIP_TRY(hipMalloc((void**)&e.dev, host.size() * sizeof(double)));
     hipError_t err = hipMemcpy(e.dev, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice);
     if (err != hipSuccess) return fail(DCTFP_ERR_HIP, "hipMemcpy(St): %s", hipGetErrorString(err));
-    if (cp == 80 && n_cols % 4 == 0) {
+    if ((cp == 80 || cp == 96) && n_cols % 4 == 0) {
         // walk_ab_kernel contracts the even and the odd half of the basis apart (kernels.hip.h, "flush"):
         //   E[d][c] = sum over even k, O[d][c] = sum over odd k of cos_m(k, c) cos_D(k, d),  d < D/2, c < ceil(m/2)
         // Tab[d] = [E[d][0..39] | O[d][0..39]] (zero past ceil(m/2); odd m: O is exactly 0 in the middle column), in
         // fragment order: frag[((q * 4 + r) * 5 + c) * 64 + lane] = Tab[16 q + 4 (lane >> 4) + r][16 c + (lane & 15)]
-        const int nt = 5, half = n_cols / 2, hm = (m + 1) / 2;
+        // (cp = 96 -- 80 < m <= 96, PROST's [3, 85] --: six column groups, halves of 48 slots)
+        const int nt = cp / 16, hs = cp / 2, half = n_cols / 2, hm = (m + 1) / 2;
         e.frag_groups = (half + 15) / 16;
-        std::vector<double> tab((size_t)half * 80, 0.0);
+        std::vector<double> tab((size_t)half * cp, 0.0);
         std::vector<long double> ce(hm), co(hm);
         for (int d = 0; d < half; ++d) {
             for (int c = 0; c < hm; ++c) ce[c] = co[c] = 0.0L;
@@ -363,8 +365,8 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
                 for (int c = 0; c < hm; ++c) dst[c] += a[c] * b;
             }
             for (int c = 0; c < hm; ++c) {
-                tab[(size_t)d * 80 + c] = (double)ce[c];
-                tab[(size_t)d * 80 + 40 + c] = (m - 1 - c == c) ? 0.0 : (double)co[c];
+                tab[(size_t)d * cp + c] = (double)ce[c];
+                tab[(size_t)d * cp + hs + c] = (m - 1 - c == c) ? 0.0 : (double)co[c];
             }
         }
         // (two groups of zeros behind the last one: the flush requests its fragments a few k-steps ahead without a clamp)
@@ -374,7 +376,7 @@ int get_st(dctfp_ctx* ctx, int n_cols, int m, StEntry** out) {
                 for (int c = 0; c < nt; ++c)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int d = 16 * q + 4 * (lane >> 4) + r, col = 16 * c + (lane & 15);
-                        if (d < half) fr[(((size_t)q * 4 + r) * nt + c) * 64 + lane] = tab[(size_t)d * 80 + col];
+                        if (d < half) fr[(((size_t)q * 4 + r) * nt + c) * 64 + lane] = tab[(size_t)d * cp + col];
                     }
         err = hipMalloc((void**)&e.frag, fr.size() * sizeof(double));
         if (err == hipSuccess) err = hipMemcpy(e.frag, fr.data(), fr.size() * sizeof(double), hipMemcpyHostToDevice);
@@ -778,6 +780,7 @@ int dctfp_get_option(dctfp_ctx* ctx, const char* name, int64_t* value) try {
     if (n == "path") *value = ctx->opt_path;
     else if (n == "last_path") *value = ctx->last_path;
     else if (n == "last_gen_fused") *value = ctx->last_gen_fused;
+    else if (n == "last_walk_groups") *value = ctx->last_walk_groups;
     else if (n == "gen_fuse") *value = ctx->opt_gen_fuse;
     else if (n == "small_one") *value = ctx->opt_small_one;
     else if (n == "last_small_one") *value = ctx->last_small_one;
@@ -875,7 +878,9 @@ bool walk_shape(const dctfp_layer& ly) {
     return false;
 #endif
     if (ly.dtype == DCTFP_F64) return false;  // float64 rows: the general kernel (6.73 against 5.73 TB/s through this one's double build)
-    return ly.n_keep == 3 && ly.m_keep > 64 && ly.m_keep <= 80 && ly.n_cols >= 512 && ly.n_cols <= 2560 && ly.n_cols % 4 == 0;
+    // (80 < m <= 96 -- PROST's [3, 85] --: the builds with six column groups, float32 rows only; round 5)
+    const int m_max = ly.dtype == DCTFP_F32 ? 96 : 80;
+    return ly.n_keep == 3 && ly.m_keep > 64 && ly.m_keep <= m_max && ly.n_cols >= 512 && ly.n_cols <= 2560 && ly.n_cols % 4 == 0;
 }
 
 // Shapes the general walk kernel (walk_gen_kernel) takes: float32 / float64 rows, n = 2 .. 8, whatever width and m fit the LDS
@@ -1134,7 +1139,7 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
         const bool rows_ok = walk_rows_ok(ctx, g, max_len_all);
         const bool walk_ok = !trivial && walk_shape(g) && vec_ok && rows_ok;
         const bool use_walk = walk_ok && walk_by_path(ctx, n_jobs);
-        if (two_source && !(use_walk && g.dtype == DCTFP_F32))  // (dctfp_quantize_windows has asked takes_two_sources() before anything was launched)
+        if (two_source && !(use_walk && g.dtype == DCTFP_F32 && m <= 80))  // (dctfp_quantize_windows has asked takes_two_sources() before anything was launched)
             return fail(DCTFP_ERR_UNSUPPORTED, "internal: two-source pieces outside the walk kernel");
         int gen_vec = 0, gen_waves = 0, gen_slots = 0;
         if (!trivial && !walk_ok && rows_ok && n >= 2 && m >= 2 && (g.dtype == DCTFP_F32 || g.dtype == DCTFP_F64)) {
@@ -1228,7 +1233,7 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
             wg_per_cu = use_gen ? std::max<int64_t>(1, std::min<int64_t>(20 / gen_waves, (int64_t)(kGenLdsBudget / (gen_slots * gen_slot_bytes(n, m, gen_waves, gen_vec) + 64))))
                                 : (walk_s == 3 ? 5 : (walk_s == 5 ? 3 : 1));
             // jobs per flush: 4 = the rows of an MFMA tile (a flush costs the same MFMAs for 1..4 jobs)
-            walk_g = ctx->opt_ab_group && !two_source ? (int)ctx->opt_ab_group : 4;
+            walk_g = ctx->opt_ab_group && !two_source && m <= 80 ? (int)ctx->opt_ab_group : 4;
             for (int64_t j = 0; j < n_jobs;) {
                 const int64_t d = j % n_domains;
                 Walk& wk = hwalk[n_walks++];
@@ -1501,6 +1506,7 @@ int quantize_impl(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_layers, i
 
         ctx->last_path = (use_walk || use_gen) ? 2 : 1;
         ctx->last_gen_fused = gen_fuse ? 1 : 0;
+        ctx->last_walk_groups = use_walk ? (m > 80 ? 6 : 5) : 0;
         ctx->walk_launches += (use_walk || use_gen) ? 1 : 0;
         if (use_gen) {
             // one launch of the general walk kernel: stage A + stage B per workgroup, int8 out
@@ -1904,7 +1910,7 @@ int dctfp_quantize_windows(dctfp_ctx* ctx, const dctfp_layer* layers, int32_t n_
                 ++l1;
             const char* why = nullptr;
             if (!g.seq_data || g.dtype != DCTFP_F32) why = "windows are averaged in float32 (as dctfp_stitch)";
-            else if (!walk_shape(g)) why = "kept sizes / width outside the one-launch kernel's (n = 3, 64 < m <= 80, 512 <= D <= 2560, D % 4 == 0)";
+            else if (!walk_shape(g) || g.m_keep > 80) why = "kept sizes / width outside the one-launch kernel's (n = 3, 64 < m <= 80, 512 <= D <= 2560, D % 4 == 0)";
             else if (!rows_aligned16(layers + l0, l1 - l0, n_win, nullptr)) why = "rows are not 16-byte aligned";
             else if (!walk_rows_ok(ctx, g, max_len)) why = "a domain above 8 192 rows";
             else if (!walk_by_path(ctx, (int64_t)(l1 - l0) * n_domains)) why = "fewer than 256 jobs (layers x domains) in the call";

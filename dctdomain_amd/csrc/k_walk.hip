@@ -8,7 +8,7 @@ template <typename T, int S, int G, int NT, int UNROLL>
 void launch_walk_impl(const WParams& p, bool fused, bool mfma_a = false) {
     static const InvTab<3> inv = make_inv<3>();
 #ifdef DCTFP_EXPERIMENTS
-    if constexpr (sizeof(T) == 4 && UNROLL == 8 && G == 4) {
+    if constexpr (sizeof(T) == 4 && UNROLL == 8 && G == 4 && NT == 5) {
         if (fused && mfma_a) {  // stage A on the matrix pipe (experiment of round 3: DESIGN.md section 4)
             hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb,
                                p.walks, p.runs, p.pieces, p.stf, p.out, p.n_cols, p.ld, p.m, inv, p.degenerate);
@@ -18,7 +18,7 @@ void launch_walk_impl(const WParams& p, bool fused, bool mfma_a = false) {
 #else
     (void)mfma_a;
 #endif
-    if constexpr (sizeof(T) == 4 && UNROLL == 8 && G == 4) {
+    if constexpr (sizeof(T) == 4 && UNROLL == 8 && G == 4 && NT == 5) {
         if (p.two_source) {  // pieces that are the mean of two windows' rows (dctfp_quantize_windows): builds of their own
             if (fused)
                 hipLaunchKernelGGL((walk_ab_kernel<T, S, G, NT, UNROLL, true, false, true>), dim3(p.grid), dim3(S * 64), 0, p.stream, p.jobs, p.jobb,
@@ -63,6 +63,13 @@ int launch_walk(const WParams& p, int dtype, int s, int g, int unroll, bool fuse
         if (s == 3) h ? launch_walk_impl<_Float16, 3, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 3, 4, 5, 8>(p, fused);
         else if (s == 5) h ? launch_walk_impl<_Float16, 5, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 5, 4, 5, 8>(p, fused);
         else h ? launch_walk_impl<_Float16, 10, 4, 5, 8>(p, fused) : launch_walk_impl<bf16_t, 10, 4, 5, 8>(p, fused);
+        return DCTFP_OK;
+    }
+    if (p.m > 80) {   // six column groups (80 < m <= 96: PROST's [3, 85]): float32 rows, four jobs per flush, eight rows in flight
+        if (g != 4 || p.two_source) return launch_fail(err, DCTFP_ERR_INVALID, "walk kernel: m = %d with %d jobs per flush / two-source pieces", p.m, g);
+        if (s == 3) launch_walk_impl<float, 3, 4, 6, 8>(p, fused);
+        else if (s == 5) launch_walk_impl<float, 5, 4, 6, 8>(p, fused);
+        else launch_walk_impl<float, 10, 4, 6, 8>(p, fused);
         return DCTFP_OK;
     }
     if (s == 3 && g == 4) return launch_walk_u<3, 4>(p, unroll, fused, mfma_a);

@@ -1090,8 +1090,11 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
     constexpr int VEC = 4, NK = 2;
     constexpr int WCH = 64 * VEC;  // channels per wave
     // per wave and slot: 256 t values (later reused for the wave's partial 3 x (NT*16) block) + 256 state bytes
-    static_assert(3 * NT * 16 <= WCH, "partial Z block must fit the slot it reuses");
-    __shared__ double lds_t[S][G][WCH];
+    // (NT = 6 -- 80 < m <= 96, PROST's [3, 85] -- : the partial block is 288 values, the slot grows with it)
+    constexpr int SLOT = 3 * NT * 16 > WCH ? 3 * NT * 16 : WCH;
+    constexpr int HS = NT * 8;     // slots of the table's E half (and of its O half): 40 at NT = 5, 48 at NT = 6
+    static_assert(NT == 5 || NT == 6, "five or six 16-column groups: [E | O] halves of 40 or 48 slots");
+    __shared__ double lds_t[S][G][SLOT];
     __shared__ uint32_t lds_c[S][G][WCH / 4];
     // The flush has no workgroup barrier (see its end): `lds_arrived` counts the waves that have stored their partial blocks,
     // `lds_done` the jobs whose rows are written -- over all flushes of the workgroup so far.
@@ -1499,7 +1502,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
             // of pair k for row j, three tiles (j = 0, 1, 2) per column group -- 15 MFMAs per k-step whatever `pending` is
             // (rows of jobs that are not there are computed on stale slots and never stored).
             {
-                static_assert(NT == 5, "slots 0..39 = E, 40..79 = O: the middle column group is half and half");
+                // (NT = 5: slots 0..39 = E, 40..79 = O -- the middle column group is half and half; NT = 6: 0..47 = E, 48..95 = O)
                 static_assert(G >= 1 && G <= 4, "one MFMA row per job of the flush");
                 // (the lane index through an opaque copy: everything the flush derives from it -- slot, masks, LDS and fragment
                 //  offsets -- would otherwise be hoisted to the top of the kernel and held in registers through the row stream,
@@ -1555,8 +1558,12 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                             const double ax = fma(fold_sign, ym, y);  // blocks 0, 1 of the middle column group: u, blocks 2, 3: v
                             // 3 * NT independent accumulators between two uses of one
 #pragma unroll
-                            for (int c = 0; c < NT; ++c)
-                                acc[jr][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(c < 2 ? au : (c == 2 ? ax : av), bq[r % DEPTH][c], acc[jr][c], 0, 0, 0);
+                            for (int c = 0; c < NT; ++c) {
+                                if constexpr (NT == 5)
+                                    acc[jr][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(c < 2 ? au : (c == 2 ? ax : av), bq[r % DEPTH][c], acc[jr][c], 0, 0, 0);
+                                else
+                                    acc[jr][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(c < NT / 2 ? au : av, bq[r % DEPTH][c], acc[jr][c], 0, 0, 0);
+                            }
                         }
                         fetch_b(bq[r % DEPTH], 4 * qi + r + DEPTH);
                     }
@@ -1586,7 +1593,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
                 const bool valid0 = lane < hm;
                 const bool valid1 = lane < hm && (m - 1 - lane) != lane;  // odd m: the middle column is its own mirror (O = 0 there)
                 int8_t* __restrict__ o = out + jobb[group_job + g].out_off;
-                static_assert(DCTFP_MAX_M_K <= 128 && NT * 16 <= 80, "lanes 0 .. 39 hold a row");
+                static_assert(DCTFP_MAX_M_K <= 128 && HS <= 48, "lanes 0 .. 47 hold a row (wave_min_max48)");
                 for (int j0 = 0; j0 < 3; j0 += ROWS) {
                     double v0[ROWS], v1[ROWS], mn[ROWS], mx[ROWS];
                     bool nan_here[ROWS];
@@ -1598,7 +1605,7 @@ __global__ __launch_bounds__(S * 64, S >= 10 ? 3 : DCTFP_WALK_MIN_WAVES) void wa
 #pragma unroll
                             for (int w = 0; w < S; ++w) {
                                 ze += lds_t[w][g][j * (NT * 16) + lane];
-                                zo += lds_t[w][g][j * (NT * 16) + 40 + lane];
+                                zo += lds_t[w][g][j * (NT * 16) + HS + lane];
                             }
                         }
                         v0[jj] = ze + zo;

@@ -324,7 +324,8 @@ int dctfp_crash_handler(int enable);
  *
  * What a user of the drop-in may want:
  *   "path"         0 (default) = by shape: the walk kernel (stage A + stage B in one launch, nothing but int8 written)
- *                  for n = 3, 64 < m <= 80, float32 / float16 / bfloat16 rows, 512 <= D <= 2560 and calls of 256 jobs
+ *                  for n = 3, 64 < m <= 80 (float32 rows: <= 96 -- PROST's [3, 85]; "last_walk_groups" reads 5 or 6),
+ *                  float32 / float16 / bfloat16 rows, 512 <= D <= 2560 and calls of 256 jobs
  *                  (layers x domains) or more -- domains above 8 192 rows are cut out of such a call and run on their own;
  *                  stage A -> scratch -> stage B otherwise.
  *                  1 = always the two-kernel path; 2 = the walk kernel wherever its shapes allow (any number of jobs)

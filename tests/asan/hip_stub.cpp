@@ -95,7 +95,9 @@ void emulate_walk(const std::string& name, dim3 grid, void** a) {
     const int S = template_int(name, "walk_ab_kernel", 0), G = template_int(name, "walk_ab_kernel", 1);
     if (S * 256 < n_cols) { fprintf(stderr, "stub: %d waves cannot cover %d channels\n", S, n_cols); abort(); }
     const int groups = (n_cols / 2 + 15) / 16;
-    touch(stf, (size_t)(groups * 4 + 4) * 5 * 64 * sizeof(double));  // fragments up to 4 k-steps past the last group
+    const int nt_w = template_int(name, "walk_ab_kernel", 2);   // five or six column groups ([E | O] halves of 40 / 48 slots)
+    if ((nt_w != 5 && nt_w != 6) || m > nt_w * 16 || (nt_w == 6 && m <= 80)) { fprintf(stderr, "stub: walk_ab_kernel build of %d column groups for m = %d\n", nt_w, m); abort(); }
+    touch(stf, (size_t)(groups * 4 + 4) * nt_w * 64 * sizeof(double));  // fragments up to 4 k-steps past the last group
     ++g_walk_launches;
     for (unsigned b = 0; b < grid.x; ++b) {
         const Run run = runs[b];

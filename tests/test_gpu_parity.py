@@ -60,7 +60,7 @@ def walk_eligible(case, layers):
     float32 rows read 4 channels per lane, 512 <= D <= 2560, no domain above 8192 rows -- judged on the LAST layer group,
     the one `last_path` reports."""
     x, n, m = layers[-1], case['qdim'][-2], case['qdim'][-1]
-    return n == 3 and 64 < m <= 80 and x.dtype == np.float32 and 512 <= x.shape[1] <= 2560 and x.shape[1] % 4 == 0 \
+    return n == 3 and 64 < m <= 96 and x.dtype == np.float32 and 512 <= x.shape[1] <= 2560 and x.shape[1] % 4 == 0 \
         and x.shape[0] <= 8192 and len(case['keys']) > 0
 
 

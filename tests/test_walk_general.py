@@ -46,7 +46,7 @@ def _lds_fits(n, m, D, esz):
 def _general_last_group(case, layers):
     """Is the LAST layer group of the case one the general kernel takes (what `last_path` reports)?"""
     x, n, m = layers[-1], case['qdim'][-2], case['qdim'][-1]
-    tuned = n == 3 and 64 < m <= 80 and 512 <= x.shape[1] <= 2560 and x.shape[1] % 4 == 0
+    tuned = n == 3 and 64 < m <= (96 if x.dtype == np.float32 else 80) and 512 <= x.shape[1] <= 2560 and x.shape[1] % 4 == 0
     return (not tuned) and n >= 2 and m >= 2 and x.dtype in (np.float32, np.float64) and x.shape[0] <= 8192 \
         and len(case['keys']) > 0 and _lds_fits(n, m, x.shape[1], x.dtype.itemsize)
 
@@ -56,6 +56,7 @@ def test_goldens_through_the_general_walk_kernel(dd):
     ctx = dd.get_context(torch.cuda.current_device())
     ctx.set_option('path', 2)
     seen = set()
+    six_groups = {'qdim_3x85_L64_D640', 'qdim_3x85_L300_D1280'}
     try:
         for case in ALL_OK:
             layers = gu.build_layers(case)
@@ -69,6 +70,10 @@ def test_goldens_through_the_general_walk_kernel(dd):
             out = dd.quantize_batch(lbs, table, ctx=ctx).cpu().numpy()
             if _general_last_group(case, layers):
                 assert ctx.get_option('last_path') == 2, f"{case['id']} did not run a walk kernel"
+                assert ctx.get_option('last_walk_groups') == 0, case['id']
+                seen.add(case['id'])
+            elif case['id'] in six_groups:      # [3, 85] at D = 640 / 1280: walk_ab_kernel's builds with six column groups (round 5)
+                assert ctx.get_option('last_path') == 2 and ctx.get_option('last_walk_groups') == 6, case['id']
                 seen.add(case['id'])
             got, off = {}, 0
             for i in range(len(layers)):
@@ -123,6 +128,12 @@ SHAPES = [  # (id, qdim of the two layers, D, storage, min rows)
     ('f64_rows_3x80_D1280', [3, 80, 3, 80], 1280, np.float64, 12),         # walk_ab_kernel<double>
     ('f64_rows_5x44_D640', [5, 44, 5, 44], 640, np.float64, 12),
     ('mixed_5x44_then_3x80_D640', [5, 44, 3, 80], 640, np.float32, 12),    # two layer groups: general, then tuned
+    # round 5: 80 < m <= 96 through walk_ab_kernel's builds with six column groups ([E | O] halves of 48 slots)
+    ('prost_3x85_D640', [3, 85, 3, 85], 640, np.float32, 12),
+    ('prost_3x85_D2560', [3, 85, 3, 85], 2560, np.float32, 12),
+    ('3x96_D1280', [3, 96, 3, 96], 1280, np.float32, 12),
+    ('3x81_then_3x80_D1284', [3, 81, 3, 80], 1284, np.float32, 12),        # six groups, then five; a width that ends inside a pair group
+    ('3x85_f64_rows_D640', [3, 85, 3, 85], 640, np.float64, 12),           # float64 rows stay with the general kernel
 ]
 
 
@@ -147,13 +158,14 @@ def test_general_shapes_in_batches_default_dispatch(dd, name, qdim, D, dtype, lo
     # batch: their stage A reads the rows of a protein once for all of its domains)
     # Round 5: for n <= 5 it streams such proteins as FUSED walks (rows read once, the whole protein collected beside the parts).
     n_last, m_last = qdim[2], qdim[3]
-    tuned_last = n_last == 3 and 64 < m_last <= 80 and 512 <= D <= 2560 and dtype == np.float32     # walk_ab_kernel's own shape
+    tuned_last = n_last == 3 and 64 < m_last <= 96 and 512 <= D <= 2560 and dtype == np.float32     # walk_ab_kernel's own shapes (m > 80: six column groups)
     expect_fused = 0 if tuned_last else int(n_last <= 5)
     ctx.set_option('path', 2)
     try:
         out = dd.quantize_batch(lbs, table, ctx=ctx).cpu().numpy()
         assert ctx.get_option('last_path') == 2, name
         assert ctx.get_option('last_gen_fused') == expect_fused, name
+        assert ctx.get_option('last_walk_groups') == ((6 if m_last > 80 else 5) if tuned_last else 0), name
         if expect_fused:                      # ... and every job on its own when asked to: the same bytes
             ctx.set_option('gen_fuse', 0)
             try:
@@ -208,8 +220,8 @@ def test_general_kernel_nan_inf_and_constant_channels(dd):
         np.testing.assert_array_equal(out[s].astype(np.int64), q[f'1-{lens[s]}'])
 
 
-@pytest.mark.parametrize('qdim,D', [([5, 44, 5, 44], 2560), ([3, 85, 3, 85], 1280), ([4, 80, 4, 80], 640), ([2, 30, 5, 44], 1280)],
-                         ids=['5x44_D2560', '3x85_D1280', '4x80_D640', '2x30_5x44_D1280'])
+@pytest.mark.parametrize('qdim,D', [([5, 44, 5, 44], 2560), ([3, 100, 3, 100], 1280), ([4, 80, 4, 80], 640), ([2, 30, 5, 44], 1280)],
+                         ids=['5x44_D2560', '3x100_D1280', '4x80_D640', '2x30_5x44_D1280'])
 def test_fused_general_kernel_on_reccut_shaped_lists(dd, qdim, D):
     """PROST-shaped kept sizes on RecCut-shaped domain lists (1-6 parts tiling the protein, some discontinuous, + the whole
     protein; single-domain proteins between them) in one call: the general kernel's fused walks ("path" = 2) against the

@@ -35,8 +35,12 @@ for w in (sys.argv[1:] or ['c5', 'c4', 'c3']):
             res[path] = 5 * nbytes / (time.perf_counter() - t0) / 1e9
             assert ctx.get_option('last_path') == min(path, 2)
             fused = ctx.get_option('last_gen_fused')
+            if path == 2:
+                groups = ctx.get_option('last_walk_groups')
             outs[path] = out.clone()
         ctx.set_option('path', 0)
         ctx.set_option('gen_fuse', 1)
-        print(f'   [{n},{m}]  two kernels {res[1]:6.0f} GB/s   general walk kernel: fused walks {res[2]:6.0f} GB/s, every job on its own {res[3]:6.0f} GB/s   '
+        print(f'   [{n},{m}]  two kernels {res[1]:6.0f} GB/s   ' + (f'walk_ab_kernel ({groups} column groups) {res[2]:6.0f} GB/s   ' if groups else
+              f'general walk kernel: fused walks {res[2]:6.0f} GB/s, every job on its own {res[3]:6.0f} GB/s   ') +
+              f''
               f'identical={bool((outs[1] == outs[2]).all() and (outs[1] == outs[3]).all())}', flush=True)
