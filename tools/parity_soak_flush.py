@@ -18,7 +18,7 @@ def make_protein(seed, D):
     near = 0.9 * np.exp(-np.abs(i[:, None] - i[None, :]) / 12.0)
     same = (i[:, None] // blk) == (i[None, :] // blk)
     if rng.random() < 0.3:          # two blocks that belong together although apart in sequence: discontinuous domains
-        a, b = rng.integers(0, max(1, L // blk + 1), size=2)
+        a, b = 0, max(0, (L - 1) // blk)          # (head and tail: the flanks of a double cut -> one discontinuous domain)
         same |= (np.isin(i[:, None] // blk, [a, b])) & (np.isin(i[None, :] // blk, [a, b]))
     cm = near + 0.3 * rng.random((L, L)) * same + 0.02 * rng.random((L, L))
     if rng.random() < 0.25:         # plateaus: a map quantised to a hundred levels (ties at the selection's threshold)
