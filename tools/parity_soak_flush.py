@@ -17,10 +17,11 @@ def make_protein(seed, D):
     blk = int(rng.integers(70, 180))
     near = 0.9 * np.exp(-np.abs(i[:, None] - i[None, :]) / 12.0)
     same = (i[:, None] // blk) == (i[None, :] // blk)
-    if rng.random() < 0.3:          # two blocks that belong together although apart in sequence: discontinuous domains
-        a, b = 0, max(0, (L - 1) // blk)          # (head and tail: the flanks of a double cut -> one discontinuous domain)
-        same |= (np.isin(i[:, None] // blk, [a, b])) & (np.isin(i[None, :] // blk, [a, b]))
     cm = near + 0.3 * rng.random((L, L)) * same + 0.02 * rng.random((L, L))
+    if rng.random() < 0.3 and L >= 3 * blk:   # head and tail fold onto each other (the flanks of a double cut: one discontinuous domain)
+        head, tail = i < blk, i >= L - blk
+        cross = (head[:, None] & tail[None, :]) | (tail[:, None] & head[None, :])
+        cm = np.where(cross & (rng.random((L, L)) < 0.08), 0.65 + 0.3 * rng.random((L, L)), cm)
     if rng.random() < 0.25:         # plateaus: a map quantised to a hundred levels (ties at the selection's threshold)
         cm = np.round(cm * 97) / 97
     cm = np.clip(0.5 * (cm + cm.T), 0, 1).astype(np.float32)
