@@ -64,8 +64,11 @@ def tensor_table(seq):
         return ptrs, meta
     h = helper()
     if h is not None:
-        h.fill(seq, ptrs.ctypes.data, meta.ctypes.data, n)
-        return ptrs, meta
+        try:
+            h.fill(seq, ptrs.ctypes.data, meta.ctypes.data, n)
+            return ptrs, meta
+        except RuntimeError:         # (a tensor ATen would not describe -- sparse, ...: attribute by attribute, and whoever reads the table refuses it)
+            pass
     if not all(map(torch.is_tensor, seq)):
         for i, t in enumerate(seq):          # (mixed lists are rare: entry by entry)
             if torch.is_tensor(t):

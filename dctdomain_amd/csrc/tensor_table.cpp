@@ -17,6 +17,7 @@
 #include <torch/csrc/autograd/python_variable.h>
 
 #include <cstdint>
+#include <exception>
 
 namespace {
 
@@ -36,6 +37,7 @@ PyObject* fill(PyObject*, PyObject* args) {
     int64_t* meta = reinterpret_cast<int64_t*>(static_cast<uintptr_t>(meta_addr));
     PyObject** items = PySequence_Fast_ITEMS(seq);
     Py_ssize_t n_tensors = 0;
+    try {   // (a sparse or otherwise exotic tensor makes ATen throw from stride() / data_ptr(): a Python error, not std::terminate)
     for (Py_ssize_t i = 0; i < n; ++i) {
         int64_t* m = meta + 6 * i;
         if (!THPVariable_Check(items[i])) {
@@ -55,6 +57,11 @@ PyObject* fill(PyObject*, PyObject* args) {
         const c10::Device dev = t.device();
         m[5] = (int64_t)t.scalar_type() | ((int64_t)dev.type() << 8) | ((int64_t)(dev.has_index() ? dev.index() + 1 : 0) << 16);
         ++n_tensors;
+    }
+    } catch (const std::exception& e) {
+        Py_DECREF(seq);
+        PyErr_SetString(PyExc_RuntimeError, e.what());
+        return nullptr;
     }
     Py_DECREF(seq);
     return PyLong_FromSsize_t(n_tensors);
